@@ -1,0 +1,294 @@
+/*
+ * gnss_oracle.c -- scalar-C restatement of the fork's GNSS code-correlation path.
+ * TEST INFRASTRUCTURE ONLY (see armfft_oracle.h).
+ *
+ * The reference holds no golden vector for this path ("parity unpinned by the reference"):
+ * getCode is pinned by the public IS-GPS-200 first-10-chips table (tests/test_oracle_gnss.py),
+ * everything else by synthetic scenes with known truth.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "armfft_oracle.h"
+
+#define ORC_PI 3.14159265358979323846
+
+/* GPS L1 C/A Gold code: getCode (gnss_codes.c:969-1030).  Two 10-stage LFSRs, all-ones start,
+ * G1 feedback from stages {2,9}, G2 from {1,2,5,7,8,9} (0-based), chip = G1[9]^G2[s0]^G2[s1],
+ * logic 1 -> +1, logic 0 -> -1 (:1016-1018), sample-and-hold by samples_per_chip. */
+static const int k_sats[37][2] = {
+    {1, 5}, {2, 6}, {3, 7}, {4, 8}, {0, 8}, {1, 9}, {0, 7}, {1, 8}, {2, 9}, {1, 2}, {2, 3}, {4, 5}, {5, 6},
+    {6, 7}, {7, 8}, {8, 9}, {0, 3}, {1, 4}, {2, 5}, {3, 6}, {4, 7}, {5, 8}, {0, 2}, {3, 5}, {4, 6}, {5, 7},
+    {6, 8}, {7, 9}, {0, 5}, {1, 6}, {2, 7}, {3, 8}, {4, 9}, {3, 9}, {0, 6}, {1, 7}, {3, 9}};
+
+void orc_get_code(int num, int spc, int prn, int *out)
+{
+  int g1[10], g2[10];
+  for (int i = 0; i < 10; i++) g1[i] = g2[i] = 1;
+  int k = 0;
+  if (spc < 1) spc = 1;
+  for (int i = 0; i < num; i++) {
+    int val = (g1[9] + g2[k_sats[prn - 1][0]] + g2[k_sats[prn - 1][1]]) % 2;
+    int chip = val ? 1 : -1;
+    int f1 = (g1[2] + g1[9]) % 2;
+    int f2 = (g2[1] + g2[2] + g2[5] + g2[7] + g2[8] + g2[9]) % 2;
+    for (int j = 9; j > 0; j--) {
+      g1[j] = g1[j - 1];
+      g2[j] = g2[j - 1];
+    }
+    g1[0] = f1;
+    g2[0] = f2;
+    for (int j = 0; j < spc; j++) out[k++] = chip;
+  }
+}
+
+/* mix_prn (gnss_codes.c:1032-1063): replica = code * e^{j theta n}, double recursive phasor,
+ * renormalised every sample, FS = 1.023e6 * spc. */
+void orc_mix_prn(const int32_t *code, double doppler_hz, double phase_deg, orc_c32 *sig, int size, int spc)
+{
+  double FS = 1.023e6 * spc;
+  double dth = 2.0 * ORC_PI * doppler_hz / FS;
+  double ci = cos(dth), si = sin(dth);
+  double pc = cos(phase_deg * ORC_PI / 180.0), ps = sin(phase_deg * ORC_PI / 180.0);
+  for (int n = 0; n < size; n++) {
+    double a = (double)code[n];
+    sig[n].r = (float)(a * pc);
+    sig[n].i = (float)(a * ps);
+    double npc = pc * ci - ps * si, nps = pc * si + ps * ci;
+    pc = npc;
+    ps = nps;
+    double na = 1.0 / sqrt(pc * pc + ps * ps);
+    pc *= na;
+    ps *= na;
+  }
+}
+
+/* synth_gps_prn (gnss_codes.c:1066-1071) */
+void orc_synth_gps_prn(int prn, float doppler, int size, orc_c32 *replica, int spc)
+{
+  int *code = (int *)malloc(sizeof(int) * (size_t)(size + spc));
+  orc_get_code(size / spc, spc, prn, code);
+  orc_mix_prn(code, doppler, 0, replica, size, spc);
+  free(code);
+}
+
+static inline float c32_mag(orc_c32 v) { return sqrtf(v.r * v.r + v.i * v.i); } /* gnss_codes.c:27-29 */
+
+/* find_top2_peaks_cplx / _real (gnss_codes.c:1144-1190): sequential, ">=" keeps the LAST maximal
+ * index, second peak must be > pk_sep away from the best AT THE TIME it is seen. */
+static void top2_step(float magn, int m, int pk_sep, float *v1, int *i1, float *v2, int *i2)
+{
+  if (magn >= *v1) {
+    if (*i1 != -1 && abs(m - *i1) > pk_sep) { *v2 = *v1; *i2 = *i1; }
+    *v1 = magn;
+    *i1 = m;
+  } else if (magn > *v2) {
+    if (magn != *v1 && abs(m - *i1) > pk_sep) { *v2 = magn; *i2 = m; }
+  }
+}
+
+int orc_find_top2_peaks_cplx(const orc_c32 *data, int n, int pk_sep, orc_top2 *pk)
+{
+  if (n <= 0 || !data || !pk) return -1;
+  float v1 = -1e10f, v2 = -1e10f;
+  int i1 = -1, i2 = -1;
+  for (int m = 0; m < n; m++) top2_step(c32_mag(data[m]), m, pk_sep, &v1, &i1, &v2, &i2);
+  pk->val1 = v1; pk->idx1 = i1; pk->val2 = v2; pk->idx2 = i2;
+  return 0;
+}
+
+int orc_find_top2_peaks_real(const float *data, int n, int pk_sep, orc_top2 *pk)
+{
+  if (n <= 0 || !data || !pk) return -1;
+  float v1 = -1e10f, v2 = -1e10f;
+  int i1 = -1, i2 = -1;
+  for (int m = 0; m < n; m++) top2_step(data[m], m, pk_sep, &v1, &i1, &v2, &i2);
+  pk->val1 = v1; pk->idx1 = i1; pk->val2 = v2; pk->idx2 = i2;
+  return 0;
+}
+
+/* compute_snr_cplx (gnss_codes.c:1110-1125): 10 log10(peak / mean off-peak magnitude) */
+double orc_compute_snr_cplx(const orc_c32 *conv, int n, double peak, int peak_loc)
+{
+  double sum = 0;
+  for (int i = 0; i < n; i++) {
+    float magn = c32_mag(conv[i]);
+    if (abs(i - peak_loc) > 2) sum += magn;
+  }
+  double mean = sum / (n - 5);
+  return 10.0 * log10(peak / mean);
+}
+
+/* InterpolateCodePhase (gnss_codes.c:1096-1108) */
+double orc_interpolate_code_phase(uint32_t index, double early, double prompt, double late)
+{
+  double x;
+  if (late > early) {
+    x = 0.5 * (late - early) / (prompt - early);
+    return index + (x / 3.0) * (2.0 * x + 2.0);
+  }
+  x = 0.5 * (late - early) / (prompt - late);
+  return index + (x / 3.0) * (-2.0 * x + 2.0);
+}
+
+/* fft_c32 (CMSIS/CMSIS.cpp:218-234): the radix-2 FFT on interleaved c32 */
+void orc_fft_c32(int size, orc_c32 *w, int fwd) { orc_cfft_radix2_f32((float *)w, (uint32_t)size, fwd ? 0 : 1, 1); }
+
+/* One (prn, doppler) cell row exactly as read_ors does it (CMSIS/CMSIS.cpp:706-737): carrier at
+ * -doppler on the REPLICA, FFT(replica), FFT(signal), S*conj(R), IFFT, top-2 peak search. */
+int orc_acquire_cell_reference(const orc_c32 *signal, int size, int prn, float doppler, int spc, orc_top2 *pk,
+                               float *mag_out)
+{
+  orc_c32 *repli = (orc_c32 *)malloc(sizeof(orc_c32) * (size_t)size);
+  orc_c32 *signl = (orc_c32 *)malloc(sizeof(orc_c32) * (size_t)size);
+  orc_c32 *prod = (orc_c32 *)malloc(sizeof(orc_c32) * (size_t)size);
+  if (!repli || !signl || !prod) return -1;
+  /* read_ors passes -prn2acq.doppler where .doppler = -(true Doppler); net: replica carrier = +f_d */
+  orc_synth_gps_prn(prn, doppler, size, repli, spc);
+  memcpy(signl, signal, sizeof(orc_c32) * (size_t)size);
+  orc_fft_c32(size, repli, 1);
+  orc_fft_c32(size, signl, 1);
+  for (int i = 0; i < size; i++) { /* mult(signl, get_conj(repli)) */
+    float ar = signl[i].r, ai = signl[i].i, br = repli[i].r, bi = -repli[i].i;
+    prod[i].r = ar * br - ai * bi;
+    prod[i].i = ar * bi + ai * br;
+  }
+  orc_fft_c32(size, prod, 0);
+  orc_find_top2_peaks_cplx(prod, size, 3, pk);
+  if (mag_out)
+    for (int i = 0; i < size; i++) mag_out[i] = c32_mag(prod[i]);
+  free(repli);
+  free(signl);
+  free(prod);
+  return 0;
+}
+
+/* The fused form the GPU kernel implements:
+ *   per Doppler bin: wipe-off on the SIGNAL, x[n] e^{-j 2 pi f n / FS} (the form of
+ *     recover_prn_phase_deg_with_doppler, CMSIS/CMSIS.cpp:384-404, phase continuous over all n_ms),
+ *     coherent fold of the n_ms one-ms blocks (linearity of CMSIS.cpp:1157-1169's frequency-domain
+ *     sum), zero-pad samples_per_ms -> fft_len (CMSIS.cpp:1154-1160), ONE forward FFT;
+ *   per PRN: multiply by conj(FFT(code, zero Doppler, zero-padded)), inverse FFT (1/N), |.|,
+ *     find_top2_peaks (pk_sep 3), compute_snr, InterpolateCodePhase; best Doppler bin per PRN =
+ *     largest val1 (lowest bin wins ties).
+ * Phases are evaluated directly in double (no recursive phasor): the gate downstream is identical
+ * PRN / code phase / Doppler bin, not bit-equal correlation values. */
+int orc_acquire_fused(const orc_c32 *signal, int n_ms, int spm, int fft_len, int spc, const int *prns, int n_prn,
+                      const float *dopplers, int n_dop, orc_acq_result *best, orc_acq_result *all)
+{
+  if (spm > fft_len || n_ms < 1) return -1;
+  double FS = 1.023e6 * spc;
+  orc_c32 *codes = (orc_c32 *)calloc((size_t)n_prn * fft_len, sizeof(orc_c32));
+  orc_c32 *z = (orc_c32 *)malloc(sizeof(orc_c32) * (size_t)fft_len);
+  orc_c32 *prod = (orc_c32 *)malloc(sizeof(orc_c32) * (size_t)fft_len);
+  int *chips = (int *)malloc(sizeof(int) * (size_t)(fft_len + spc));
+  if (!codes || !z || !prod || !chips) return -1;
+  for (int p = 0; p < n_prn; p++) {
+    orc_c32 *c = codes + (size_t)p * fft_len;
+    orc_get_code(spm / spc, spc, prns[p], chips);
+    for (int n = 0; n < spm; n++) { c[n].r = (float)chips[n]; c[n].i = 0.0f; }
+    orc_fft_c32(fft_len, c, 1);
+    best[p].peak = -1.0f;
+  }
+  for (int d = 0; d < n_dop; d++) {
+    memset(z, 0, sizeof(orc_c32) * (size_t)fft_len);
+    for (int b = 0; b < n_ms; b++) {
+      for (int m = 0; m < spm; m++) {
+        long n = (long)b * spm + m;
+        double cyc = (double)dopplers[d] * (double)n / FS;
+        cyc -= floor(cyc);
+        double th = 2.0 * ORC_PI * cyc;
+        float c = (float)cos(th), s = (float)sin(th);
+        float I = signal[n].r, Q = signal[n].i;
+        z[m].r += I * c + Q * s;
+        z[m].i += -I * s + Q * c;
+      }
+    }
+    orc_fft_c32(fft_len, z, 1);
+    for (int p = 0; p < n_prn; p++) {
+      const orc_c32 *c = codes + (size_t)p * fft_len;
+      for (int i = 0; i < fft_len; i++) {
+        float ar = z[i].r, ai = z[i].i, br = c[i].r, bi = -c[i].i;
+        prod[i].r = ar * br - ai * bi;
+        prod[i].i = ar * bi + ai * br;
+      }
+      orc_fft_c32(fft_len, prod, 0);
+      orc_top2 pk;
+      orc_find_top2_peaks_cplx(prod, fft_len, 3, &pk);
+      orc_acq_result r;
+      r.peak = pk.val1; r.second = pk.val2; r.code_phase = pk.idx1; r.second_phase = pk.idx2;
+      r.doppler_bin = d; r.prn = prns[p];
+      r.snr_db = (float)orc_compute_snr_cplx(prod, fft_len, pk.val1, pk.idx1);
+      int e = (pk.idx1 + fft_len - 1) % fft_len, l = (pk.idx1 + 1) % fft_len;
+      r.code_phase_interp = (float)orc_interpolate_code_phase((uint32_t)pk.idx1, c32_mag(prod[e]), pk.val1, c32_mag(prod[l]));
+      if (all) all[(size_t)p * n_dop + d] = r;
+      if (r.peak > best[p].peak) best[p] = r;
+    }
+  }
+  free(codes);
+  free(z);
+  free(prod);
+  free(chips);
+  return 0;
+}
+
+/* ---- resampler: iq_resamp_zp_* (up_sample.c:16-157) behind up_sample_N_to_M (gnss_codes.c:868-884) ---- */
+static double sinc_pi(double x) { return fabs(x) < 1e-12 ? 1.0 : sin(ORC_PI * x) / (ORC_PI * x); }
+static double blackman_sym(int n, int half)
+{
+  int N = 2 * half, k = n + half;
+  double phi = (2.0 * ORC_PI * k) / (double)(N - 1);
+  return 0.42 - 0.5 * cos(phi) + 0.08 * cos(2.0 * phi);
+}
+static int reflect_index(int idx, int N)
+{
+  if (N <= 1) return 0;
+  while (idx < 0 || idx >= N) {
+    if (idx < 0) idx = -idx - 1;
+    if (idx >= N) idx = 2 * N - 1 - idx;
+  }
+  return idx;
+}
+static void resamp_forward(double dt, int half, double c, const orc_c32 *in, int nin, orc_c32 *out, int nout)
+{
+  for (int k = 0; k < nout; k++) {
+    double t = (double)k * dt;
+    int ti = (int)floor(t);
+    double frac = t - (double)ti, ai = 0, aq = 0, ws = 0;
+    for (int m = -half; m < half; m++) {
+      double x = (double)m - frac;
+      double h = (2.0 * c) * sinc_pi(2.0 * c * x) * blackman_sym(m, half);
+      int idx = reflect_index(ti + m, nin);
+      ai += h * (double)in[idx].r;
+      aq += h * (double)in[idx].i;
+      ws += h;
+    }
+    double inv = fabs(ws) > 1e-15 ? 1.0 / ws : 1.0;
+    out[k].r = (float)(ai * inv);
+    out[k].i = (float)(aq * inv);
+  }
+}
+
+/* zero-phase N -> M resample, 12 taps, cutoff 0.45; n_out = llround(n_in * M/N) as in
+ * iq_resamp_process_zero_phase (up_sample.c:115-157).  (up_sample_N_to_M's own cap uses the
+ * INTEGER quotient M_out/N_in, gnss_codes.c:879, which truncates 10230->16384 to 10230 outputs;
+ * the restatement follows up_sample_10k_to_16k's uncapped behaviour, :886-904.) */
+int orc_up_sample_n_to_m(const orc_c32 *in, int n_in, orc_c32 *out, int n_out)
+{
+  const int half = 6;
+  const double cutoff = 0.45;
+  if (n_in <= 0 || n_out <= 0) return 0;
+  orc_c32 *y = (orc_c32 *)malloc(sizeof(orc_c32) * (size_t)n_out);
+  orc_c32 *yr = (orc_c32 *)malloc(sizeof(orc_c32) * (size_t)n_out);
+  orc_c32 *yr2 = (orc_c32 *)malloc(sizeof(orc_c32) * (size_t)n_out);
+  if (!y || !yr || !yr2) return 0;
+  resamp_forward((double)n_in / (double)n_out, half, cutoff, in, n_in, y, n_out);
+  for (int k = 0; k < n_out; k++) yr[k] = y[n_out - 1 - k];
+  resamp_forward(1.0, half, cutoff, yr, n_out, yr2, n_out);
+  for (int k = 0; k < n_out; k++) out[k] = yr2[n_out - 1 - k];
+  free(y);
+  free(yr);
+  free(yr2);
+  return n_out;
+}
