@@ -1,0 +1,282 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native CMSIS FFT hot path.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of synthetic input: the BASELINE.json
+configs[1] workload, `arm_cfft_f32` forward, 4096 points x 65536 transforms, in place, resident in
+HBM (2 GiB per GPU).  With N GPUs every rank owns its own 65536-transform batch (weak scaling,
+independent batches, no data-path collective); `value` is the whole-job GFLOP/s at the
+reference's 5*N*log2(N) accounting.  Rank 0 prints ONE JSON line.
+
+Extra objects on that line:
+  roofline     -- dominant kernel vs the 8 TB/s HBM peak: algorithmic bytes (16*N per transform)
+                  / average launch duration measured with HIP events on the launch stream.
+  cpu_baseline -- the reference's own generic-C arm_cfft_f32 (oracle/_ref, kind "reference") or,
+                  when that library was not built, the repo's CPU restatement (kind "port"),
+                  timed on a bounded sample on this host's cores (rank 0, N = 1 only).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s measured copy
+
+WORKLOADS = {
+    # name: (kind, fft_len, batch, bytes per point moved (read+write), flops per transform factor)
+    "cfft_f32_4096x65536": dict(kind="f32", n=4096, batch=65536, dtype="f32"),
+    "cfft_q15_4096x65536": dict(kind="q15", n=4096, batch=65536, dtype="q15"),
+    "cfft_q31_4096x65536": dict(kind="q31", n=4096, batch=65536, dtype="q31"),
+    "rfft_f32_16384x16384": dict(kind="rfft", n=16384, batch=16384, dtype="f32"),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cfft_f32_4096x65536", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="override the batch (debug only; the line says so)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+# ---------------------------------------------------------------------------------------------
+# CPU baseline (checker code, timed beside the GPU number; never part of the measured GPU path)
+# ---------------------------------------------------------------------------------------------
+def cpu_baseline(kind, n, seconds):
+    import numpy as np
+    ref_so = os.path.join(ROOT, "oracle", "_ref", "libcmsis_ref.so")
+    orc_so = os.path.join(ROOT, "oracle", "liboracle.so")
+    use_ref = os.path.exists(ref_so) and kind in ("f32", "q15", "q31") and n <= 4096
+    use_ref = use_ref or (os.path.exists(ref_so) and kind == "rfft" and n <= 4096)
+    if use_ref:
+        L = ctypes.CDLL(ref_so)
+        which = "reference"
+    elif os.path.exists(orc_so):
+        L = ctypes.CDLL(orc_so)
+        which = "port"
+    else:
+        return None
+    cores = max(1, min(16, os.cpu_count() or 1))
+    per_thread = 256  # transforms per call per thread
+    rng = np.random.default_rng(0x5EED0001)
+    if kind == "f32":
+        cn = min(n, 4096) if which == "reference" else n
+        proto = rng.uniform(-1, 1, (per_thread, 2 * cn)).astype(np.float32)
+        if which == "reference":
+            call = lambda a: L.ref_cfft_f32(a.ctypes.data_as(ctypes.c_void_p), cn, per_thread, 0, 1)
+        else:
+            call = lambda a: L.orc_cfft_f32_batch(a.ctypes.data_as(ctypes.c_void_p), cn, per_thread, 0, 1)
+        flops = 5.0 * cn * np.log2(cn)
+        sample = "arm_cfft_f32 forward, %d points" % cn
+    elif kind in ("q15", "q31"):
+        dt = np.int16 if kind == "q15" else np.int32
+        amp = 16384 if kind == "q15" else 2 ** 30
+        cn = n
+        proto = rng.integers(-amp, amp, (per_thread, 2 * cn)).astype(dt)
+        if which == "reference":
+            f = getattr(L, "ref_cfft_" + kind)
+            call = lambda a: f(a.ctypes.data_as(ctypes.c_void_p), cn, per_thread, 0, 1)
+        else:
+            f = getattr(L, "orc_cfft_%s_batch" % kind)
+            call = lambda a: f(a.ctypes.data_as(ctypes.c_void_p), cn, per_thread, 0, 1, 0)
+        flops = 5.0 * cn * np.log2(cn)
+        sample = "arm_cfft_%s forward, %d points" % (kind, cn)
+    else:  # rfft: the reference stops at 4096 real points
+        cn = min(n, 4096)
+        proto = rng.uniform(-1, 1, (per_thread, cn)).astype(np.float32)
+        out = np.zeros_like(proto)
+        if which == "reference":
+            call = lambda a: L.ref_rfft_fast_f32(a.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), cn, per_thread, 0)
+        else:
+            call = lambda a: L.orc_rfft_fast_f32_batch(a.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), cn, per_thread, 0)
+        flops = 2.5 * cn * np.log2(cn)
+        sample = "arm_rfft_fast_f32 forward, %d real points (reference maximum)" % cn
+
+    busy = [0.0] * cores
+    done = [0] * cores
+    deadline = time.perf_counter() + seconds
+
+    def worker(i):
+        work = proto.copy()
+        call(work)  # warm-up (tables, caches)
+        while time.perf_counter() < deadline:
+            np.copyto(work, proto)  # fresh input each pass (untimed): repeated in-place FFTs overflow
+            t0 = time.perf_counter()
+            call(work)
+            busy[i] += time.perf_counter() - t0
+            done[i] += per_thread
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(cores)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    rate = sum(done[i] / busy[i] for i in range(cores) if busy[i] > 0)  # transforms/s over all threads
+    return {
+        "value": round(rate * flops / 1e9, 3),
+        "unit": "GFLOP/s",
+        "cores": cores,
+        "kind": which,
+        "sample": "%s; %d threads x %d-transform batches for %.0f s (%d transforms), gcc -O2 scalar C, %.1f us/transform/core"
+                  % (sample, cores, per_thread, seconds, sum(done), 1e6 * cores / rate),
+    }
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import fft_amd
+    from fft_amd import lib
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: fft_amd has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert lib.arm_fft_mi355_set_device(local_rank) == 0, fft_amd.last_error()
+
+    wl = dict(WORKLOADS[args.workload])
+    if args.batch:
+        wl["batch"] = args.batch
+    kind, n, batch = wl["kind"], wl["n"], wl["batch"]
+    K, W = args.steps, args.warmup
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    gen = torch.Generator(device="cuda").manual_seed(0x5EED0001 + rank)
+
+    # ---- synthetic input, resident in HBM before the timed region ----
+    if kind == "f32":
+        S = fft_amd.arm_cfft_instance_f32()
+        assert lib.arm_cfft_init_f32(ctypes.byref(S), n) == 0
+        # uniform(-1,1) scaled down so that K+W unnormalised forward passes (x64 RMS each) stay finite
+        chunk = 16
+        amp = 2.0 ** -48
+        data = ((torch.rand((batch, 2 * n), device="cuda", generator=gen) * 2 - 1) * amp).contiguous()
+        step = lambda: lib.arm_cfft_f32_dev(ctypes.byref(S), ctypes.c_void_p(data.data_ptr()), batch, 0, 1, stream)
+        rescale = lambda: data.mul_(2.0 ** (-6 * chunk))
+        bytes_per_xform, flops_per_xform = 16 * n, 5.0 * n * np.log2(n)
+        kernel_name = "cfft_f32_kernel<12, false>"
+    elif kind in ("q15", "q31"):
+        I = fft_amd.arm_cfft_instance_q15 if kind == "q15" else fft_amd.arm_cfft_instance_q31
+        S = I()
+        assert getattr(lib, "arm_cfft_init_" + kind)(ctypes.byref(S), n) == 0
+        dt, amp = (torch.int16, 16384) if kind == "q15" else (torch.int32, 2 ** 30)
+        data = torch.randint(-amp, amp, (batch, 2 * n), device="cuda", generator=gen, dtype=dt)
+        fn = getattr(lib, "arm_cfft_%s_dev" % kind)
+        step = lambda: fn(ctypes.byref(S), ctypes.c_void_p(data.data_ptr()), batch, 0, 1, stream)
+        rescale, chunk = None, 1 << 30  # fixed point scales itself by 1/N per pass
+        bytes_per_xform, flops_per_xform = (8 if kind == "q15" else 16) * n, 5.0 * n * np.log2(n)
+        kernel_name = "cfft_fixed_kernel<%s, 12, false>" % kind.upper()
+    else:
+        S = fft_amd.arm_rfft_fast_instance_f32()
+        assert lib.arm_rfft_fast_init_f32(ctypes.byref(S), n) == 0
+        data = (torch.rand((batch, n), device="cuda", generator=gen) * 2 - 1).contiguous()
+        out = torch.empty_like(data)
+        step = lambda: lib.arm_rfft_fast_f32_dev(ctypes.byref(S), ctypes.c_void_p(data.data_ptr()), ctypes.c_void_p(out.data_ptr()), batch, 0, stream)
+        rescale, chunk = None, 1 << 30
+        bytes_per_xform, flops_per_xform = 8 * n, 2.5 * n * np.log2(n)
+        kernel_name = "rfft_f32_kernel<13, false>"
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    state = {"passes": 0, "kernel_ms": 0.0}
+
+    def do_steps(m, timed):
+        while m > 0:
+            todo = min(m, chunk - state["passes"] % chunk) if rescale else m
+            if timed:
+                ev0.record()
+            for _ in range(todo):
+                assert step() == 0, fft_amd.last_error()
+            if timed:
+                ev1.record()
+            state["passes"] += todo
+            m -= todo
+            if rescale and state["passes"] % chunk == 0:
+                rescale()  # keeps f32 data finite; inside the wall-clock region, outside the kernel events
+            if timed:
+                ev1.synchronize()
+                state["kernel_ms"] += ev0.elapsed_time(ev1)
+
+    do_steps(W, False)
+    barrier()
+    t0 = time.perf_counter()
+    do_steps(K, True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = state["kernel_ms"]
+
+    if world > 1:
+        t = torch.tensor([elapsed, kernel_ms], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, kernel_ms = float(t[0]), float(t[1])
+
+    finite = True
+    if kind in ("f32", "rfft"):
+        finite = bool(torch.isfinite(data if kind == "f32" else out).all())
+
+    if rank == 0:
+        total_xforms = batch * K * world
+        gflops = total_xforms * flops_per_xform / elapsed / 1e9
+        launch_s = kernel_ms / 1e3 / K
+        achieved = batch * bytes_per_xform / launch_s / 1e9
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tp):
+            try:
+                traffic = json.load(open(tp)).get(args.workload)
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "batched cfft_f32 4096-pt GFLOP/s (5NlogN) + % HBM roofline; GNSS acq cells/s"
+                      if args.workload == "cfft_f32_4096x65536" else args.workload + " GFLOP/s",
+            "value": round(gflops, 2),
+            "unit": "GFLOP/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": round(1e3 * elapsed / K, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": wl["dtype"],
+            "data": "synthetic",
+            "config": {"workload": args.workload, "fft_len": n, "batch_per_gpu": batch, "direction": "forward",
+                       "in_place": kind != "rfft", "sharding": "independent batches per GPU, no collective",
+                       "output_finite": finite},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": kernel_name,
+                         "algorithmic_bytes_per_launch": batch * bytes_per_xform,
+                         "avg_launch_ms": round(1e3 * launch_s, 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(kind, n, args.cpu_seconds)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

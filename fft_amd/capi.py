@@ -1,0 +1,106 @@
+"""ctypes mirror of include/arm_fft_mi355.h (struct layouts = the reference's
+Include/dsp/transform_functions.h:284-298, :352-366, :416-430, :827-832)."""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int16, c_int32, c_uint8, c_uint16, c_uint32, c_void_p
+
+__all__ = [
+    "lib", "lib_path", "ARM_MATH_SUCCESS", "ARM_MATH_ARGUMENT_ERROR",
+    "arm_cfft_instance_f32", "arm_cfft_instance_q15", "arm_cfft_instance_q31", "arm_rfft_fast_instance_f32",
+    "last_error", "EXPORTED_SYMBOLS",
+]
+
+ARM_MATH_SUCCESS = 0
+ARM_MATH_ARGUMENT_ERROR = -1
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def lib_path():
+    return os.path.join(_HERE, "lib", "libarmfft_mi355.so")
+
+
+class arm_cfft_instance_f32(Structure):
+    _fields_ = [("fftLen", c_uint16), ("pTwiddle", POINTER(c_float)), ("pBitRevTable", POINTER(c_uint16)),
+                ("bitRevLength", c_uint16)]
+
+
+class arm_cfft_instance_q15(Structure):
+    _fields_ = [("fftLen", c_uint16), ("pTwiddle", POINTER(c_int16)), ("pBitRevTable", POINTER(c_uint16)),
+                ("bitRevLength", c_uint16)]
+
+
+class arm_cfft_instance_q31(Structure):
+    _fields_ = [("fftLen", c_uint16), ("pTwiddle", POINTER(c_int32)), ("pBitRevTable", POINTER(c_uint16)),
+                ("bitRevLength", c_uint16)]
+
+
+class arm_rfft_fast_instance_f32(Structure):
+    _fields_ = [("Sint", arm_cfft_instance_f32), ("fftLenRFFT", c_uint16), ("pTwiddleRFFT", POINTER(c_float))]
+
+
+_F32_SIZES = [16, 32, 64, 128, 256, 512, 1024, 2048, 4096]
+_Q15_SIZES = _F32_SIZES + [8192, 16384]
+_Q31_SIZES = _F32_SIZES + [8192]
+_RFFT_SIZES = [32, 64, 128, 256, 512, 1024, 2048, 4096]
+
+# every symbol include/arm_fft_mi355.h declares
+EXPORTED_SYMBOLS = (
+    ["arm_cfft_init_f32", "arm_cfft_f32", "arm_cfft_batch_f32", "arm_cfft_f32_dev"]
+    + ["arm_cfft_init_%d_f32" % n for n in _F32_SIZES]
+    + ["arm_cfft_init_q15", "arm_cfft_q15", "arm_cfft_batch_q15", "arm_cfft_q15_dev"]
+    + ["arm_cfft_init_%d_q15" % n for n in _Q15_SIZES]
+    + ["arm_cfft_init_q31", "arm_cfft_q31", "arm_cfft_batch_q31", "arm_cfft_q31_dev"]
+    + ["arm_cfft_init_%d_q31" % n for n in _Q31_SIZES]
+    + ["arm_rfft_fast_init_f32", "arm_rfft_fast_f32", "arm_rfft_fast_batch_f32", "arm_rfft_fast_f32_dev"]
+    + ["arm_rfft_fast_init_%d_f32" % n for n in _RFFT_SIZES]
+    + ["arm_fft_mi355_set_device", "arm_fft_mi355_warm", "arm_fft_mi355_last_error",
+       "arm_fft_mi355_set_twiddle_rounding", "arm_fft_mi355_version"]
+)
+
+
+def _load():
+    path = lib_path()
+    if not os.path.exists(path):
+        raise ImportError(
+            "%s is missing: build it with `python -m fft_amd.build` (hipcc, gfx950). "
+            "fft_amd has no CPU fallback." % path)
+    L = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+    u8, u16, u32 = c_uint8, c_uint16, c_uint32
+    for T, inst, scalar in (("f32", arm_cfft_instance_f32, c_float), ("q15", arm_cfft_instance_q15, c_int16),
+                            ("q31", arm_cfft_instance_q31, c_int32)):
+        f = getattr(L, "arm_cfft_init_" + T)
+        f.argtypes, f.restype = [POINTER(inst), u16], c_int
+        f = getattr(L, "arm_cfft_" + T)
+        f.argtypes, f.restype = [POINTER(inst), c_void_p, u8, u8], None
+        f = getattr(L, "arm_cfft_batch_" + T)
+        f.argtypes, f.restype = [POINTER(inst), c_void_p, u32, u8, u8], c_int
+        f = getattr(L, "arm_cfft_%s_dev" % T)
+        f.argtypes, f.restype = [POINTER(inst), c_void_p, u32, u8, u8, c_void_p], c_int
+    for name in EXPORTED_SYMBOLS:
+        if name.startswith("arm_cfft_init_") and name[14].isdigit():
+            T = name.rsplit("_", 1)[1]
+            inst = {"f32": arm_cfft_instance_f32, "q15": arm_cfft_instance_q15, "q31": arm_cfft_instance_q31}[T]
+            f = getattr(L, name)
+            f.argtypes, f.restype = [POINTER(inst)], c_int
+        if name.startswith("arm_rfft_fast_init_") and name[19].isdigit():
+            f = getattr(L, name)
+            f.argtypes, f.restype = [POINTER(arm_rfft_fast_instance_f32)], c_int
+    R = arm_rfft_fast_instance_f32
+    L.arm_rfft_fast_init_f32.argtypes, L.arm_rfft_fast_init_f32.restype = [POINTER(R), u16], c_int
+    L.arm_rfft_fast_f32.argtypes, L.arm_rfft_fast_f32.restype = [POINTER(R), c_void_p, c_void_p, u8], None
+    L.arm_rfft_fast_batch_f32.argtypes, L.arm_rfft_fast_batch_f32.restype = [POINTER(R), c_void_p, c_void_p, u32, u8], c_int
+    L.arm_rfft_fast_f32_dev.argtypes, L.arm_rfft_fast_f32_dev.restype = [POINTER(R), c_void_p, c_void_p, u32, u8, c_void_p], c_int
+    L.arm_fft_mi355_set_device.argtypes, L.arm_fft_mi355_set_device.restype = [c_int], c_int
+    L.arm_fft_mi355_warm.argtypes, L.arm_fft_mi355_warm.restype = [c_int, u32], c_int
+    L.arm_fft_mi355_last_error.argtypes, L.arm_fft_mi355_last_error.restype = [], c_char_p
+    L.arm_fft_mi355_set_twiddle_rounding.argtypes, L.arm_fft_mi355_set_twiddle_rounding.restype = [c_int], c_int
+    L.arm_fft_mi355_version.argtypes, L.arm_fft_mi355_version.restype = [], c_char_p
+    return L
+
+
+lib = _load()
+
+
+def last_error():
+    return lib.arm_fft_mi355_last_error().decode()

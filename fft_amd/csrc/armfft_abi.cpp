@@ -1,0 +1,621 @@
+// armfft_abi.cpp -- the C ABI of libarmfft_mi355.so (include/arm_fft_mi355.h): host logic only.
+//
+// Mirrors the reference's init/execute interface (Include/dsp/transform_functions.h; bodies in
+// Source/TransformFunctions/arm_cfft_init_*.c, arm_cfft_*.c, arm_rfft_fast_*.c) and routes every
+// execute call to the HIP kernels.  There is NO CPU fallback: if no GPU is usable the execute
+// functions fail loudly (arm_status / arm_fft_mi355_last_error, message on stderr).
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <mutex>
+#include <vector>
+
+#include "armfft_internal.h"
+
+namespace armfft {
+
+// ------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------
+static thread_local char t_err[512] = "";
+
+void set_error(const char *fmt, ...)
+{
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(t_err, sizeof(t_err), fmt, ap);
+  va_end(ap);
+  fprintf(stderr, "libarmfft_mi355: %s\n", t_err);
+}
+
+bool hip_ok(hipError_t e, const char *what)
+{
+  if (e == hipSuccess) return true;
+  set_error("%s failed: %s", what, hipGetErrorString(e));
+  return false;
+}
+
+// ------------------------------------------------------------------------------------------
+// host tables (what pTwiddle / pBitRevTable point to).  The reference's definitions live in the
+// constant blob Source/CommonTables/arm_common_tables.c; here they are generated once per size:
+//   f32  twiddle[2i] = cos(2 pi i/N), [2i+1] = sin(2 pi i/N)            (arm_common_tables.h:63-84)
+//   rfft twiddle[2i] = sin(2 pi i/N), [2i+1] = cos(2 pi i/N), i < N/2   (:151-165)
+//   q15/q31: 3N/4 (cos, sin) pairs * 2^15 / 2^31, +1.0 saturated; rounding floor (default) or
+//            nearest -- arm_fft_mi355_set_twiddle_rounding                (:88-130)
+//   f32 bit-reversal index table: swap pairs (byte offsets) realising the radix-(2|4),8,8.. digit
+//            reversal, same format arm_bitreversal_32 consumes (arm_bitreversal2.c:84-108)
+//   fixed-point index table: plain bit-reversal swap pairs (arm_bitreversal2.c:123-148)
+// ------------------------------------------------------------------------------------------
+static std::mutex g_mu;
+static int g_tw_rounding = 0;
+
+struct HostTables {
+  std::vector<float> tw_f32, tw_rfft;
+  std::vector<int16_t> tw_q15;
+  std::vector<int32_t> tw_q31;
+  std::vector<uint16_t> br_f32, br_fixed;
+};
+static HostTables g_host[kMaxLog + 2];
+
+static int ilog2u(uint32_t n)
+{
+  int l = 0;
+  while ((1u << l) < n) l++;
+  return l;
+}
+static bool is_pow2(uint32_t n) { return n && !(n & (n - 1)); }
+
+static void exact_cs(uint32_t i, uint32_t N, double *c, double *s)
+{
+  if ((4u * i) % N == 0) {
+    static const double cq[4] = {1, 0, -1, 0}, sq[4] = {0, 1, 0, -1};
+    uint32_t q = (4u * i / N) & 3u;
+    *c = cq[q];
+    *s = sq[q];
+  } else {
+    double a = 2.0 * M_PI * (double)i / (double)N;
+    *c = cos(a);
+    *s = sin(a);
+  }
+}
+
+static int64_t to_fixed(double v, double scale, int rounding, int64_t lo, int64_t hi)
+{
+  double s = v * scale;
+  double r = rounding ? floor(s + 0.5) : floor(s);
+  if (r > (double)hi) r = (double)hi;
+  if (r < (double)lo) r = (double)lo;
+  return (int64_t)r;
+}
+
+static uint32_t brev(uint32_t v, int bits)
+{
+  uint32_t r = 0;
+  for (int i = 0; i < bits; i++) r |= ((v >> i) & 1u) << (bits - 1 - i);
+  return r;
+}
+
+// position of output bin k before the reordering (see scrambled_pos in armfft_f32.hip)
+static uint32_t f32_pos_of_bin(uint32_t k, int logn)
+{
+  int l0 = logn % 3, n8 = logn / 3;
+  uint32_t d0 = k & ((1u << l0) - 1), rest = k >> l0, low = 0;
+  for (int s = 0; s < n8; s++) {
+    low = (low << 3) | (rest & 7u);
+    rest >>= 3;
+  }
+  return (d0 << (3 * n8)) | low;
+}
+
+static const float *host_tw_f32(int logn)
+{
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto &t = g_host[logn].tw_f32;
+  if (t.empty()) {
+    uint32_t N = 1u << logn;
+    t.resize(2 * N);
+    for (uint32_t i = 0; i < N; i++) {
+      double a = 2.0 * M_PI * (double)i / (double)N;
+      t[2 * i] = (float)cos(a);
+      t[2 * i + 1] = (float)sin(a);
+    }
+  }
+  return t.data();
+}
+
+static const float *host_tw_rfft(int logn_real)
+{
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto &t = g_host[logn_real].tw_rfft;
+  if (t.empty()) {
+    uint32_t N = 1u << logn_real;
+    t.resize(N);
+    for (uint32_t i = 0; i < N / 2; i++) {
+      double a = 2.0 * M_PI * (double)i / (double)N;
+      t[2 * i] = (float)sin(a);
+      t[2 * i + 1] = (float)cos(a);
+    }
+  }
+  return t.data();
+}
+
+static const int16_t *host_tw_q15(int logn)
+{
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto &t = g_host[logn].tw_q15;
+  if (t.empty()) {
+    uint32_t N = 1u << logn;
+    t.resize(3 * N / 2);
+    for (uint32_t i = 0; i < 3 * N / 4; i++) {
+      double c, s;
+      exact_cs(i, N, &c, &s);
+      t[2 * i] = (int16_t)to_fixed(c, 32768.0, g_tw_rounding, -32768, 32767);
+      t[2 * i + 1] = (int16_t)to_fixed(s, 32768.0, g_tw_rounding, -32768, 32767);
+    }
+  }
+  return t.data();
+}
+
+static const int32_t *host_tw_q31(int logn)
+{
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto &t = g_host[logn].tw_q31;
+  if (t.empty()) {
+    uint32_t N = 1u << logn;
+    t.resize(3 * N / 2);
+    for (uint32_t i = 0; i < 3 * N / 4; i++) {
+      double c, s;
+      exact_cs(i, N, &c, &s);
+      t[2 * i] = (int32_t)to_fixed(c, 2147483648.0, g_tw_rounding, INT32_MIN, INT32_MAX);
+      t[2 * i + 1] = (int32_t)to_fixed(s, 2147483648.0, g_tw_rounding, INT32_MIN, INT32_MAX);
+    }
+  }
+  return t.data();
+}
+
+// Swap-pair tables use 16-bit byte offsets (8 bytes per complex f32/q31 point), so they can only
+// describe N <= 8192; for 16384 the instance carries a NULL table and length 0 (the reference's
+// own 16384 table is declared uint32_t and unusable through this field, arm_common_tables.h:265).
+static const uint16_t *host_br_f32(int logn, uint16_t *len)
+{
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (logn > 13) { *len = 0; return nullptr; }
+  auto &t = g_host[logn].br_f32;
+  if (t.empty()) {
+    uint32_t N = 1u << logn;
+    std::vector<uint32_t> perm(N);  // out[k] = in[perm[k]]
+    for (uint32_t k = 0; k < N; k++) perm[k] = f32_pos_of_bin(k, logn);
+    std::vector<uint8_t> done(N, 0);
+    for (uint32_t s = 0; s < N; s++) {
+      if (done[s] || perm[s] == s) { done[s] = 1; continue; }
+      uint32_t a = s;
+      done[a] = 1;
+      for (;;) {
+        uint32_t b = perm[a];
+        if (b == s) break;
+        t.push_back((uint16_t)(8 * a));
+        t.push_back((uint16_t)(8 * b));
+        done[b] = 1;
+        a = b;
+      }
+    }
+    if (t.empty()) t.push_back(0), t.push_back(0);
+  }
+  *len = (uint16_t)t.size();
+  return t.data();
+}
+
+static const uint16_t *host_br_fixed(int logn, uint16_t *len)
+{
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (logn > 13) { *len = 0; return nullptr; }
+  auto &t = g_host[logn].br_fixed;
+  if (t.empty()) {
+    uint32_t N = 1u << logn;
+    for (uint32_t i = 0; i < N; i++) {
+      uint32_t j = brev(i, logn);
+      if (i < j) {
+        t.push_back((uint16_t)(8 * i));
+        t.push_back((uint16_t)(8 * j));
+      }
+    }
+  }
+  *len = (uint16_t)t.size();
+  return t.data();
+}
+
+// ------------------------------------------------------------------------------------------
+// device plans: per GPU, per size, generated ON the device at first use and kept for the life
+// of the process (a few hundred KiB in total).
+// ------------------------------------------------------------------------------------------
+constexpr int kMaxDev = 16;
+struct DevPlans {
+  float2 *tw_f32[kMaxLog + 2] = {};
+  float2 *tw_rfft[kMaxLog + 2] = {};
+  int16_t *tw_q15[kMaxLog + 2] = {};
+  int32_t *tw_q31[kMaxLog + 2] = {};
+  void *stage = nullptr;  // grow-only staging buffers for the host-pointer entry points
+  size_t stage_bytes = 0;
+  void *stage2 = nullptr;
+  size_t stage2_bytes = 0;
+};
+static DevPlans g_dev[kMaxDev];
+static std::mutex g_dev_mu;
+
+static bool current_device(int *dev)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+    set_error("no HIP device available: libarmfft_mi355 has no CPU path");
+    return false;
+  }
+  if (!hip_ok(hipGetDevice(dev), "hipGetDevice")) return false;
+  if (*dev < 0 || *dev >= kMaxDev) {
+    set_error("device index %d out of range", *dev);
+    return false;
+  }
+  return true;
+}
+
+static const float2 *dev_tw_f32(int logn)
+{
+  int dev;
+  if (!current_device(&dev)) return nullptr;
+  std::lock_guard<std::mutex> lk(g_dev_mu);
+  float2 *&p = g_dev[dev].tw_f32[logn];
+  if (!p) {
+    uint32_t N = 1u << logn;
+    if (!hip_ok(hipMalloc((void **)&p, sizeof(float2) * N), "hipMalloc(twiddle)")) { p = nullptr; return nullptr; }
+    if (!hip_ok(launch_gen_twiddle_f32(p, N, nullptr), "twiddle generation") || !hip_ok(hipStreamSynchronize(nullptr), "sync")) {
+      (void)hipFree(p);
+      p = nullptr;
+    }
+  }
+  return p;
+}
+
+static const float2 *dev_tw_rfft(int logn_real)
+{
+  int dev;
+  if (!current_device(&dev)) return nullptr;
+  std::lock_guard<std::mutex> lk(g_dev_mu);
+  float2 *&p = g_dev[dev].tw_rfft[logn_real];
+  if (!p) {
+    uint32_t N = 1u << logn_real;
+    if (!hip_ok(hipMalloc((void **)&p, sizeof(float2) * (N / 2)), "hipMalloc(rfft twiddle)")) { p = nullptr; return nullptr; }
+    if (!hip_ok(launch_gen_twiddle_rfft(p, N, nullptr), "rfft twiddle generation") || !hip_ok(hipStreamSynchronize(nullptr), "sync")) {
+      (void)hipFree(p);
+      p = nullptr;
+    }
+  }
+  return p;
+}
+
+// Fixed-point tables are generated on the device and then CHECKED against the host table the
+// instance points to: a double-precision cos/sin that differs in the last bit between libm and
+// the device could move a floor() across an integer (about 1e-7 per q31 entry), and bit-exact
+// output needs bit-exact twiddles.  On any mismatch the host table is uploaded instead.
+template <typename T>
+static T *dev_tw_fixed(T *&slot, int logn, const T *host, hipError_t (*gen)(T *, uint32_t, int, hipStream_t))
+{
+  if (slot) return slot;
+  uint32_t N = 1u << logn;
+  size_t count = 3 * (size_t)N / 2, bytes = count * sizeof(T);
+  T *p = nullptr;
+  if (!hip_ok(hipMalloc((void **)&p, bytes), "hipMalloc(fixed twiddle)")) return nullptr;
+  std::vector<T> back(count);
+  bool ok = hip_ok(gen(p, N, g_tw_rounding, nullptr), "fixed twiddle generation") &&
+            hip_ok(hipMemcpy(back.data(), p, bytes, hipMemcpyDeviceToHost), "hipMemcpy(D2H twiddle)");
+  if (ok && memcmp(back.data(), host, bytes) != 0) ok = hip_ok(hipMemcpy(p, host, bytes, hipMemcpyHostToDevice), "hipMemcpy(H2D twiddle)");
+  if (!ok) {
+    (void)hipFree(p);
+    return nullptr;
+  }
+  slot = p;
+  return slot;
+}
+
+static const int16_t *dev_tw_q15(int logn)
+{
+  int dev;
+  if (!current_device(&dev)) return nullptr;
+  const int16_t *host = host_tw_q15(logn);
+  std::lock_guard<std::mutex> lk(g_dev_mu);
+  return dev_tw_fixed<int16_t>(g_dev[dev].tw_q15[logn], logn, host, launch_gen_twiddle_q15);
+}
+
+static const int32_t *dev_tw_q31(int logn)
+{
+  int dev;
+  if (!current_device(&dev)) return nullptr;
+  const int32_t *host = host_tw_q31(logn);
+  std::lock_guard<std::mutex> lk(g_dev_mu);
+  return dev_tw_fixed<int32_t>(g_dev[dev].tw_q31[logn], logn, host, launch_gen_twiddle_q31);
+}
+
+// staging for host-pointer calls; serialised per device by g_stage_mu (these entry points are the
+// compatibility path, not the fast path)
+static std::mutex g_stage_mu;
+static void *stage_buffer(int dev, size_t bytes, int which)
+{
+  void *&p = which ? g_dev[dev].stage2 : g_dev[dev].stage;
+  size_t &cap = which ? g_dev[dev].stage2_bytes : g_dev[dev].stage_bytes;
+  if (cap < bytes) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    if (!hip_ok(hipMalloc(&p, bytes), "hipMalloc(staging)")) return nullptr;
+    cap = bytes;
+  }
+  return p;
+}
+
+// ------------------------------------------------------------------------------------------
+// length checks
+// ------------------------------------------------------------------------------------------
+static int cfft_log(uint32_t n)
+{
+  if (!is_pow2(n)) return -1;
+  int l = ilog2u(n);
+  return (l >= kMinLog && l <= kMaxLog) ? l : -1;
+}
+
+template <typename S, typename T>
+static arm_status host_batch(const S *inst, T *p, uint32_t batch, size_t elems_per_xform,
+                             arm_status (*dev_fn)(const S *, T *, uint32_t, uint8_t, uint8_t, void *), uint8_t ifft,
+                             uint8_t bitrev)
+{
+  if (!inst || !p) {
+    set_error("null argument");
+    return ARM_MATH_ARGUMENT_ERROR;
+  }
+  if (batch == 0) return ARM_MATH_SUCCESS;
+  int dev;
+  if (!current_device(&dev)) return ARM_MATH_ARGUMENT_ERROR;
+  std::lock_guard<std::mutex> lk(g_stage_mu);
+  size_t bytes = elems_per_xform * batch * sizeof(T);
+  T *d = (T *)stage_buffer(dev, bytes, 0);
+  if (!d) return ARM_MATH_ARGUMENT_ERROR;
+  if (!hip_ok(hipMemcpy(d, p, bytes, hipMemcpyHostToDevice), "hipMemcpy(H2D)")) return ARM_MATH_ARGUMENT_ERROR;
+  arm_status s = dev_fn(inst, d, batch, ifft, bitrev, nullptr);
+  if (s != ARM_MATH_SUCCESS) return s;
+  if (!hip_ok(hipMemcpy(p, d, bytes, hipMemcpyDeviceToHost), "hipMemcpy(D2H)")) return ARM_MATH_ARGUMENT_ERROR;
+  return ARM_MATH_SUCCESS;
+}
+
+}  // namespace armfft
+
+using namespace armfft;
+
+// ==========================================================================================
+// C ABI
+// ==========================================================================================
+extern "C" {
+
+const char *arm_fft_mi355_version(void) { return "armfft_mi355 0.1 (gfx950)"; }
+const char *arm_fft_mi355_last_error(void) { return t_err; }
+
+arm_status arm_fft_mi355_set_device(int device)
+{
+  return hip_ok(hipSetDevice(device), "hipSetDevice") ? ARM_MATH_SUCCESS : ARM_MATH_ARGUMENT_ERROR;
+}
+
+arm_status arm_fft_mi355_set_twiddle_rounding(int mode)
+{
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (auto &h : g_host)
+    if (!h.tw_q15.empty() || !h.tw_q31.empty()) {
+      set_error("twiddle rounding must be chosen before the first fixed-point init");
+      return ARM_MATH_ARGUMENT_ERROR;
+    }
+  g_tw_rounding = mode ? 1 : 0;
+  return ARM_MATH_SUCCESS;
+}
+
+arm_status arm_fft_mi355_warm(int kind, uint32_t fftLen)
+{
+  int l = cfft_log(kind == 3 ? fftLen / 2 : fftLen);
+  if (l < 0) return ARM_MATH_ARGUMENT_ERROR;
+  switch (kind) {
+    case 0: return dev_tw_f32(l) ? ARM_MATH_SUCCESS : ARM_MATH_ARGUMENT_ERROR;
+    case 1: return dev_tw_q15(l) ? ARM_MATH_SUCCESS : ARM_MATH_ARGUMENT_ERROR;
+    case 2: return dev_tw_q31(l) ? ARM_MATH_SUCCESS : ARM_MATH_ARGUMENT_ERROR;
+    case 3: return (dev_tw_f32(l) && dev_tw_rfft(l + 1)) ? ARM_MATH_SUCCESS : ARM_MATH_ARGUMENT_ERROR;
+  }
+  return ARM_MATH_ARGUMENT_ERROR;
+}
+
+// ---------------- f32 complex ----------------
+arm_status arm_cfft_init_f32(arm_cfft_instance_f32 *S, uint16_t fftLen)
+{
+  if (!S) return ARM_MATH_ARGUMENT_ERROR;
+  int l = cfft_log(fftLen);
+  if (l < 0) return ARM_MATH_ARGUMENT_ERROR;  // S untouched, arm_cfft_init_f32.c:346-349
+  S->fftLen = fftLen;
+  S->pTwiddle = host_tw_f32(l);
+  S->pBitRevTable = host_br_f32(l, &S->bitRevLength);
+  return ARM_MATH_SUCCESS;
+}
+
+#define ARMFFT_INIT_N(N, T)                                                                   \
+  arm_status arm_cfft_init_##N##_##T(arm_cfft_instance_##T *S) { return arm_cfft_init_##T(S, N); }
+ARMFFT_INIT_N(4096, f32) ARMFFT_INIT_N(2048, f32) ARMFFT_INIT_N(1024, f32) ARMFFT_INIT_N(512, f32)
+ARMFFT_INIT_N(256, f32) ARMFFT_INIT_N(128, f32) ARMFFT_INIT_N(64, f32) ARMFFT_INIT_N(32, f32) ARMFFT_INIT_N(16, f32)
+
+arm_status arm_cfft_f32_dev(const arm_cfft_instance_f32 *S, float32_t *p, uint32_t batch, uint8_t ifft, uint8_t bitrev,
+                            void *stream)
+{
+  if (!S || !p) { set_error("arm_cfft_f32_dev: null argument"); return ARM_MATH_ARGUMENT_ERROR; }
+  int l = cfft_log(S->fftLen);
+  if (l < 0) { set_error("arm_cfft_f32_dev: unsupported fftLen %u", (unsigned)S->fftLen); return ARM_MATH_ARGUMENT_ERROR; }
+  const float2 *tw = dev_tw_f32(l);
+  if (!tw) return ARM_MATH_ARGUMENT_ERROR;
+  hipError_t e = launch_cfft_f32(l, reinterpret_cast<float2 *>(p), tw, batch, ifft != 0, bitrev == 0, (hipStream_t)stream);
+  return hip_ok(e, "cfft_f32 launch") ? ARM_MATH_SUCCESS : ARM_MATH_ARGUMENT_ERROR;
+}
+
+arm_status arm_cfft_batch_f32(const arm_cfft_instance_f32 *S, float32_t *p, uint32_t batch, uint8_t ifft, uint8_t bitrev)
+{
+  if (!S || cfft_log(S->fftLen) < 0) { set_error("arm_cfft_batch_f32: unsupported instance"); return ARM_MATH_ARGUMENT_ERROR; }
+  return host_batch<arm_cfft_instance_f32, float32_t>(S, p, batch, 2 * (size_t)S->fftLen, arm_cfft_f32_dev, ifft, bitrev);
+}
+
+void arm_cfft_f32(const arm_cfft_instance_f32 *S, float32_t *p1, uint8_t ifftFlag, uint8_t bitReverseFlag)
+{
+  if (!S || cfft_log(S->fftLen) < 0) return;  // silent no-op like the reference's switch (arm_cfft_f32.c:1263-1280)
+  if (arm_cfft_batch_f32(S, p1, 1, ifftFlag, bitReverseFlag) != ARM_MATH_SUCCESS) {
+    fprintf(stderr, "libarmfft_mi355: arm_cfft_f32 cannot run (%s)\n", t_err);
+    abort();  // a void entry point has no other way to refuse to return wrong data
+  }
+}
+
+// ---------------- q15 complex ----------------
+arm_status arm_cfft_init_q15(arm_cfft_instance_q15 *S, uint16_t fftLen)
+{
+  if (!S) return ARM_MATH_ARGUMENT_ERROR;
+  int l = cfft_log(fftLen);
+  if (l < 0) return ARM_MATH_ARGUMENT_ERROR;  // S untouched, arm_cfft_init_q15.c:346-349
+  S->fftLen = fftLen;
+  S->pTwiddle = host_tw_q15(l);
+  S->pBitRevTable = host_br_fixed(l, &S->bitRevLength);
+  return ARM_MATH_SUCCESS;
+}
+ARMFFT_INIT_N(16384, q15) ARMFFT_INIT_N(8192, q15) ARMFFT_INIT_N(4096, q15) ARMFFT_INIT_N(2048, q15)
+ARMFFT_INIT_N(1024, q15) ARMFFT_INIT_N(512, q15) ARMFFT_INIT_N(256, q15) ARMFFT_INIT_N(128, q15)
+ARMFFT_INIT_N(64, q15) ARMFFT_INIT_N(32, q15) ARMFFT_INIT_N(16, q15)
+
+arm_status arm_cfft_q15_dev(const arm_cfft_instance_q15 *S, q15_t *p, uint32_t batch, uint8_t ifft, uint8_t bitrev, void *stream)
+{
+  if (!S || !p) { set_error("arm_cfft_q15_dev: null argument"); return ARM_MATH_ARGUMENT_ERROR; }
+  int l = cfft_log(S->fftLen);
+  if (l < 0) { set_error("arm_cfft_q15_dev: unsupported fftLen %u", (unsigned)S->fftLen); return ARM_MATH_ARGUMENT_ERROR; }
+  const int16_t *tw = dev_tw_q15(l);
+  if (!tw) return ARM_MATH_ARGUMENT_ERROR;
+  hipError_t e = launch_cfft_q15(l, p, tw, batch, ifft != 0, bitrev != 0, (hipStream_t)stream);
+  return hip_ok(e, "cfft_q15 launch") ? ARM_MATH_SUCCESS : ARM_MATH_ARGUMENT_ERROR;
+}
+
+arm_status arm_cfft_batch_q15(const arm_cfft_instance_q15 *S, q15_t *p, uint32_t batch, uint8_t ifft, uint8_t bitrev)
+{
+  if (!S || cfft_log(S->fftLen) < 0) { set_error("arm_cfft_batch_q15: unsupported instance"); return ARM_MATH_ARGUMENT_ERROR; }
+  return host_batch<arm_cfft_instance_q15, q15_t>(S, p, batch, 2 * (size_t)S->fftLen, arm_cfft_q15_dev, ifft, bitrev);
+}
+
+void arm_cfft_q15(const arm_cfft_instance_q15 *S, q15_t *p1, uint8_t ifftFlag, uint8_t bitReverseFlag)
+{
+  if (!S || cfft_log(S->fftLen) < 0) return;  // arm_cfft_q15.c:681-721: no default case
+  if (arm_cfft_batch_q15(S, p1, 1, ifftFlag, bitReverseFlag) != ARM_MATH_SUCCESS) {
+    fprintf(stderr, "libarmfft_mi355: arm_cfft_q15 cannot run (%s)\n", t_err);
+    abort();
+  }
+}
+
+// ---------------- q31 complex ----------------
+arm_status arm_cfft_init_q31(arm_cfft_instance_q31 *S, uint16_t fftLen)
+{
+  if (!S) return ARM_MATH_ARGUMENT_ERROR;
+  int l = cfft_log(fftLen);
+  if (l < 0) return ARM_MATH_ARGUMENT_ERROR;  // S untouched, arm_cfft_init_q31.c:349-352
+  S->fftLen = fftLen;
+  S->pTwiddle = host_tw_q31(l);
+  S->pBitRevTable = host_br_fixed(l, &S->bitRevLength);
+  return ARM_MATH_SUCCESS;
+}
+ARMFFT_INIT_N(8192, q31) ARMFFT_INIT_N(4096, q31) ARMFFT_INIT_N(2048, q31) ARMFFT_INIT_N(1024, q31)
+ARMFFT_INIT_N(512, q31) ARMFFT_INIT_N(256, q31) ARMFFT_INIT_N(128, q31) ARMFFT_INIT_N(64, q31)
+ARMFFT_INIT_N(32, q31) ARMFFT_INIT_N(16, q31)
+
+arm_status arm_cfft_q31_dev(const arm_cfft_instance_q31 *S, q31_t *p, uint32_t batch, uint8_t ifft, uint8_t bitrev, void *stream)
+{
+  if (!S || !p) { set_error("arm_cfft_q31_dev: null argument"); return ARM_MATH_ARGUMENT_ERROR; }
+  int l = cfft_log(S->fftLen);
+  if (l < 0) { set_error("arm_cfft_q31_dev: unsupported fftLen %u", (unsigned)S->fftLen); return ARM_MATH_ARGUMENT_ERROR; }
+  const int32_t *tw = dev_tw_q31(l);
+  if (!tw) return ARM_MATH_ARGUMENT_ERROR;
+  hipError_t e = launch_cfft_q31(l, p, tw, batch, ifft != 0, bitrev != 0, (hipStream_t)stream);
+  return hip_ok(e, "cfft_q31 launch") ? ARM_MATH_SUCCESS : ARM_MATH_ARGUMENT_ERROR;
+}
+
+arm_status arm_cfft_batch_q31(const arm_cfft_instance_q31 *S, q31_t *p, uint32_t batch, uint8_t ifft, uint8_t bitrev)
+{
+  if (!S || cfft_log(S->fftLen) < 0) { set_error("arm_cfft_batch_q31: unsupported instance"); return ARM_MATH_ARGUMENT_ERROR; }
+  return host_batch<arm_cfft_instance_q31, q31_t>(S, p, batch, 2 * (size_t)S->fftLen, arm_cfft_q31_dev, ifft, bitrev);
+}
+
+void arm_cfft_q31(const arm_cfft_instance_q31 *S, q31_t *p1, uint8_t ifftFlag, uint8_t bitReverseFlag)
+{
+  if (!S || cfft_log(S->fftLen) < 0) return;  // arm_cfft_q31.c:718-754: no default case
+  if (arm_cfft_batch_q31(S, p1, 1, ifftFlag, bitReverseFlag) != ARM_MATH_SUCCESS) {
+    fprintf(stderr, "libarmfft_mi355: arm_cfft_q31 cannot run (%s)\n", t_err);
+    abort();
+  }
+}
+
+// ---------------- f32 real ----------------
+arm_status arm_rfft_fast_init_f32(arm_rfft_fast_instance_f32 *S, uint16_t fftLen)
+{
+  if (!S) return ARM_MATH_ARGUMENT_ERROR;  // arm_rfft_fast_init_f32.c:87
+  int l = (fftLen >= 32 && is_pow2(fftLen)) ? cfft_log(fftLen / 2u) : -1;
+  if (l < 0 || l + 1 > kMaxLog) return ARM_MATH_ARGUMENT_ERROR;  // S untouched, arm_rfft_fast_init_f32.c:366-368
+  arm_status st = arm_cfft_init_f32(&S->Sint, (uint16_t)(fftLen / 2u));
+  if (st != ARM_MATH_SUCCESS) return st;
+  S->fftLenRFFT = fftLen;
+  S->pTwiddleRFFT = host_tw_rfft(l + 1);
+  return ARM_MATH_SUCCESS;
+}
+#define ARMFFT_RINIT_N(N) \
+  arm_status arm_rfft_fast_init_##N##_f32(arm_rfft_fast_instance_f32 *S) { return arm_rfft_fast_init_f32(S, N); }
+ARMFFT_RINIT_N(32) ARMFFT_RINIT_N(64) ARMFFT_RINIT_N(128) ARMFFT_RINIT_N(256) ARMFFT_RINIT_N(512) ARMFFT_RINIT_N(1024)
+ARMFFT_RINIT_N(2048) ARMFFT_RINIT_N(4096)
+
+static int rfft_log(const arm_rfft_fast_instance_f32 *S)
+{
+  if (!S || S->fftLenRFFT < 32 || !is_pow2(S->fftLenRFFT)) return -1;
+  int l = ilog2u(S->fftLenRFFT);
+  return (l - 1 >= kMinLog && l <= kMaxLog && S->Sint.fftLen == S->fftLenRFFT / 2) ? l : -1;
+}
+
+arm_status arm_rfft_fast_f32_dev(const arm_rfft_fast_instance_f32 *S, const float32_t *p, float32_t *pOut, uint32_t batch,
+                                 uint8_t ifft, void *stream)
+{
+  if (!S || !p || !pOut) { set_error("arm_rfft_fast_f32_dev: null argument"); return ARM_MATH_ARGUMENT_ERROR; }
+  int l = rfft_log(S);
+  if (l < 0) { set_error("arm_rfft_fast_f32_dev: unsupported instance"); return ARM_MATH_ARGUMENT_ERROR; }
+  if (p == pOut) { set_error("arm_rfft_fast_f32_dev: input and output must be different buffers"); return ARM_MATH_ARGUMENT_ERROR; }
+  const float2 *tw = dev_tw_f32(l - 1), *twr = dev_tw_rfft(l);
+  if (!tw || !twr) return ARM_MATH_ARGUMENT_ERROR;
+  hipError_t e = launch_rfft_f32(l, p, pOut, tw, twr, batch, ifft != 0, (hipStream_t)stream);
+  return hip_ok(e, "rfft_f32 launch") ? ARM_MATH_SUCCESS : ARM_MATH_ARGUMENT_ERROR;
+}
+
+arm_status arm_rfft_fast_batch_f32(const arm_rfft_fast_instance_f32 *S, float32_t *p, float32_t *pOut, uint32_t batch, uint8_t ifft)
+{
+  if (!S || !p || !pOut) { set_error("arm_rfft_fast_batch_f32: null argument"); return ARM_MATH_ARGUMENT_ERROR; }
+  if (rfft_log(S) < 0) { set_error("arm_rfft_fast_batch_f32: unsupported instance"); return ARM_MATH_ARGUMENT_ERROR; }
+  if (batch == 0) return ARM_MATH_SUCCESS;
+  int dev;
+  if (!current_device(&dev)) return ARM_MATH_ARGUMENT_ERROR;
+  std::lock_guard<std::mutex> lk(g_stage_mu);
+  size_t bytes = (size_t)S->fftLenRFFT * batch * sizeof(float);
+  float *din = (float *)stage_buffer(dev, bytes, 0), *dout = (float *)stage_buffer(dev, bytes, 1);
+  if (!din || !dout) return ARM_MATH_ARGUMENT_ERROR;
+  if (!hip_ok(hipMemcpy(din, p, bytes, hipMemcpyHostToDevice), "hipMemcpy(H2D)")) return ARM_MATH_ARGUMENT_ERROR;
+  arm_status s = arm_rfft_fast_f32_dev(S, din, dout, batch, ifft, nullptr);
+  if (s != ARM_MATH_SUCCESS) return s;
+  if (!hip_ok(hipMemcpy(pOut, dout, bytes, hipMemcpyDeviceToHost), "hipMemcpy(D2H)")) return ARM_MATH_ARGUMENT_ERROR;
+  return ARM_MATH_SUCCESS;
+}
+
+void arm_rfft_fast_f32(const arm_rfft_fast_instance_f32 *S, float32_t *p, float32_t *pOut, uint8_t ifftFlag)
+{
+  if (rfft_log(S) < 0) return;
+  if (arm_rfft_fast_batch_f32(S, p, pOut, 1, ifftFlag) != ARM_MATH_SUCCESS) {
+    fprintf(stderr, "libarmfft_mi355: arm_rfft_fast_f32 cannot run (%s)\n", t_err);
+    abort();
+  }
+}
+
+}  // extern "C"

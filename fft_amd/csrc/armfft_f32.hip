@@ -1,0 +1,235 @@
+// armfft_f32.hip -- batched complex and real f32 FFT kernels for gfx950 (MI355X).
+//
+// Replaces the compute of arm_cfft_f32 (arm_cfft_f32.c:1243-1298: radix-8 butterflies
+// arm_cfft_radix8_f32.c:51-291, radix-2/4 first stage arm_cfft_f32.c:846-1201, table bit reversal
+// arm_bitreversal2.c:84-108) and arm_rfft_fast_f32 (arm_rfft_fast_f32.c:675-699, split/merge
+// :316-462) with an LDS-resident Stockham transform (fft_core_f32.hpp): each transform is read
+// from HBM once and written once (16 bytes per point), twiddles come from a device-generated,
+// L2-resident table and never from HBM in steady state.
+#include "armfft_internal.h"
+#include "fft_core_f32.hpp"
+
+namespace armfft {
+
+// Position at which arm_cfft_f32 leaves bin k when bitReverseFlag == 0: digits of k are
+// (d0 | radix-8 digits, least significant first) with d0 the radix-2/4 first-stage digit
+// (arm_cfft_f32.c:1263-1280); the position has the same digits most significant first.
+template <int LOGN>
+__device__ __forceinline__ int scrambled_pos(int k)
+{
+  constexpr int L0 = LOGN % 3, N8 = LOGN / 3;
+  int d0 = k & ((1 << L0) - 1);
+  int rest = k >> L0;
+  int low = 0;
+#pragma unroll
+  for (int s = 0; s < N8; s++) {
+    low = (low << 3) | (rest & 7);
+    rest >>= 3;
+  }
+  return (d0 << (3 * N8)) | low;
+}
+
+template <int LOGN, bool INV>
+__global__ __launch_bounds__(Plan<LOGN>::T, 4) void cfft_f32_kernel(float2 *__restrict__ data, const float2 *__restrict__ tw,
+                                                                 uint32_t batch, uint32_t ngroups, int scramble)
+{
+  using PL = Plan<LOGN>;
+  extern __shared__ __attribute__((aligned(16))) float2 lds[];
+  const int tid = threadIdx.x;
+  const float inv_n = 1.0f / (float)PL::N;
+  {
+    const uint32_t g = blockIdx.x + blockIdx.y * gridDim.x;
+    if (g >= ngroups) return;
+    const uint32_t t0 = g * PL::TPB;
+    auto ld = [&](int t, int e) -> float2 {
+      const uint32_t tr = t0 + t;
+      float2 v = make_float2(0.f, 0.f);
+      if (tr < batch) v = data[(size_t)tr * PL::N + e];
+      if (INV) v.y = -v.y;
+      return v;
+    };
+    auto st = [&](int t, int e, float2 v) {
+      const uint32_t tr = t0 + t;
+      if (INV) v = make_float2(v.x * inv_n, -v.y * inv_n);
+      if (scramble) e = scrambled_pos<LOGN>(e);
+      if (tr < batch) data[(size_t)tr * PL::N + e] = v;
+    };
+    fft_block<LOGN, false, false>(lds, tw, tid, ld, st);
+  }
+}
+
+// ---- real FFT: N real points <-> packed half spectrum, through an N/2-point complex FFT ----
+// LOGM = log2(N/2).  Forward: z = FFT(x as N/2 complex) to LDS, then the split of stage_rfft_f32
+// (arm_rfft_fast_f32.c:316-402).  Inverse: merge_rfft_f32 (:405-462) fused into the load of the
+// inverse complex FFT.
+template <int LOGM, bool INV>
+__global__ __launch_bounds__(Plan<LOGM>::T, 4) void rfft_f32_kernel(const float2 *__restrict__ in, float2 *__restrict__ out,
+                                                                 const float2 *__restrict__ tw, const float2 *__restrict__ twr,
+                                                                 uint32_t batch, uint32_t ngroups)
+{
+  using PL = Plan<LOGM>;
+  constexpr int M = PL::N;
+  extern __shared__ __attribute__((aligned(16))) float2 lds[];
+  const int tid = threadIdx.x;
+  {
+    const uint32_t g = blockIdx.x + blockIdx.y * gridDim.x;
+    if (g >= ngroups) return;
+    const uint32_t t0 = g * PL::TPB;
+    if (!INV) {
+      auto ld = [&](int t, int e) -> float2 {
+        const uint32_t tr = t0 + t;
+        return tr < batch ? in[(size_t)tr * M + e] : make_float2(0.f, 0.f);
+      };
+      auto st = [&](int t, int e, float2 v) { lds[lds_pad(t * M + e)] = v; };
+      fft_block<LOGM, false, true>(lds, tw, tid, ld, st);
+      __syncthreads();
+      // split: bin k from Z[k] and Z[M-k]
+      for (int w = tid; w < PL::TPB * M; w += PL::T) {
+        const int t = w >> LOGM, k = w & (M - 1);
+        const uint32_t tr = t0 + t;
+        const float2 A = lds[lds_pad(t * M + k)];
+        float2 o;
+        if (k == 0) {
+          o = make_float2(A.x + A.y, A.x - A.y);  // 0.5*((2 re) +- (2 im)), exact
+        } else {
+          const float2 B = lds[lds_pad(t * M + (M - k))];
+          const float2 c = twr[k];  // (sin, cos)
+          const float a = B.x - A.x, b = B.y + A.y;
+          o.x = 0.5f * (A.x + B.x + c.x * a + c.y * b);
+          o.y = 0.5f * (A.y - B.y + c.y * a - c.x * b);
+        }
+        if (tr < batch) out[(size_t)tr * M + k] = o;
+      }
+    } else {
+      const float inv_m = 1.0f / (float)M;
+      auto ld = [&](int t, int e) -> float2 {
+        const uint32_t tr = t0 + t;
+        if (tr >= batch) return make_float2(0.f, 0.f);
+        const float2 A = in[(size_t)tr * M + e];
+        float2 o;
+        if (e == 0) {
+          o = make_float2(0.5f * (A.x + A.y), 0.5f * (A.x - A.y));
+        } else {
+          const float2 B = in[(size_t)tr * M + (M - e)];
+          const float2 c = twr[e];
+          const float a = A.x - B.x, b = A.y + B.y;
+          o.x = 0.5f * (A.x + B.x - c.x * a - c.y * b);
+          o.y = 0.5f * (A.y - B.y + c.y * a - c.x * b);
+        }
+        o.y = -o.y;  // conjugate in (inverse through the forward kernel)
+        return o;
+      };
+      auto st = [&](int t, int e, float2 v) {
+        const uint32_t tr = t0 + t;
+        if (tr < batch) out[(size_t)tr * M + e] = make_float2(v.x * inv_m, -v.y * inv_m);
+      };
+      fft_block<LOGM, false, false>(lds, tw, tid, ld, st);
+    }
+  }
+}
+
+// ---- on-device twiddle generation (double precision, exact octant reduction by sincospi) ----
+__global__ void gen_twiddle_f32_kernel(float2 *tw, uint32_t n)
+{
+  uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= n) return;
+  double s, c;
+  sincospi(2.0 * (double)m / (double)n, &s, &c);
+  tw[m] = make_float2((float)c, (float)(-s));
+}
+
+__global__ void gen_twiddle_rfft_kernel(float2 *tw, uint32_t n_real)
+{
+  uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_real / 2) return;
+  double s, c;
+  sincospi(2.0 * (double)k / (double)n_real, &s, &c);
+  tw[k] = make_float2((float)s, (float)c);
+}
+
+hipError_t launch_gen_twiddle_f32(float2 *tw, uint32_t n, hipStream_t stream)
+{
+  gen_twiddle_f32_kernel<<<(n + 255) / 256, 256, 0, stream>>>(tw, n);
+  return hipGetLastError();
+}
+
+hipError_t launch_gen_twiddle_rfft(float2 *tw, uint32_t n_real, hipStream_t stream)
+{
+  gen_twiddle_rfft_kernel<<<(n_real / 2 + 255) / 256, 256, 0, stream>>>(tw, n_real);
+  return hipGetLastError();
+}
+
+// ---- launchers ----
+static dim3 grid_for(uint32_t ngroups)
+{
+  // one workgroup per group of TPB transforms; fold very large batches into grid.y
+  const uint32_t gx = ngroups < 65536u ? ngroups : 65536u;
+  return dim3(gx, (ngroups + gx - 1) / gx, 1);
+}
+
+template <int LOGN, bool INV>
+static hipError_t launch_cfft_one(float2 *data, const float2 *tw, uint32_t batch, bool scramble, hipStream_t stream)
+{
+  using PL = Plan<LOGN>;
+  static bool attr_done[16] = {false};
+  int dev = 0;
+  hipGetDevice(&dev);
+  auto kern = cfft_f32_kernel<LOGN, INV>;
+  if (PL::LDS_BYTES > 48 * 1024 && dev < 16 && !attr_done[dev]) {
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PL::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    attr_done[dev] = true;
+  }
+  const uint32_t ngroups = (batch + PL::TPB - 1) / PL::TPB;
+  kern<<<grid_for(ngroups), PL::T, PL::LDS_BYTES, stream>>>(data, tw, batch, ngroups, scramble ? 1 : 0);
+  return hipGetLastError();
+}
+
+hipError_t launch_cfft_f32(int logn, float2 *data, const float2 *tw, uint32_t batch, bool inverse, bool scramble,
+                           hipStream_t stream)
+{
+  if (batch == 0) return hipSuccess;
+  switch (logn) {
+#define C(L) \
+  case L: return inverse ? launch_cfft_one<L, true>(data, tw, batch, scramble, stream) : launch_cfft_one<L, false>(data, tw, batch, scramble, stream);
+    C(4) C(5) C(6) C(7) C(8) C(9) C(10) C(11) C(12) C(13) C(14)
+#undef C
+  }
+  return hipErrorInvalidValue;
+}
+
+template <int LOGM, bool INV>
+static hipError_t launch_rfft_one(const float2 *in, float2 *out, const float2 *tw, const float2 *twr, uint32_t batch,
+                                  hipStream_t stream)
+{
+  using PL = Plan<LOGM>;
+  static bool attr_done[16] = {false};
+  int dev = 0;
+  hipGetDevice(&dev);
+  auto kern = rfft_f32_kernel<LOGM, INV>;
+  if (PL::LDS_BYTES > 48 * 1024 && dev < 16 && !attr_done[dev]) {
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PL::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    attr_done[dev] = true;
+  }
+  const uint32_t ngroups = (batch + PL::TPB - 1) / PL::TPB;
+  kern<<<grid_for(ngroups), PL::T, PL::LDS_BYTES, stream>>>(in, out, tw, twr, batch, ngroups);
+  return hipGetLastError();
+}
+
+hipError_t launch_rfft_f32(int logn_real, const float *in, float *out, const float2 *tw_c, const float2 *tw_r,
+                           uint32_t batch, bool inverse, hipStream_t stream)
+{
+  if (batch == 0) return hipSuccess;
+  const float2 *i2 = reinterpret_cast<const float2 *>(in);
+  float2 *o2 = reinterpret_cast<float2 *>(out);
+  switch (logn_real - 1) {
+#define C(L) \
+  case L: return inverse ? launch_rfft_one<L, true>(i2, o2, tw_c, tw_r, batch, stream) : launch_rfft_one<L, false>(i2, o2, tw_c, tw_r, batch, stream);
+    C(4) C(5) C(6) C(7) C(8) C(9) C(10) C(11) C(12) C(13)
+#undef C
+  }
+  return hipErrorInvalidValue;
+}
+
+}  // namespace armfft

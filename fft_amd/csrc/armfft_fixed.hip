@@ -1,0 +1,533 @@
+// armfft_fixed.hip -- batched q15 / q31 complex FFT kernels for gfx950 (MI355X), bit-exact with
+// the reference's generic-C fixed-point path.
+//
+// arm_cfft_q15 (arm_cfft_q15.c:671-726) and arm_cfft_q31 (arm_cfft_q31.c:708-759) are radix-4
+// DIF transforms whose result depends on WHERE each stage scales and truncates, so the stage
+// structure is reproduced exactly: a radix-2 pre-stage for N = 2*4^k (arm_cfft_radix4by2_*,
+// arm_cfft_q15.c:736-931, arm_cfft_q31.c:767-885), then first / middle / last radix-4 stages
+// (arm_cfft_radix4_q15.c:572-970 and :1434-1813, arm_cfft_radix4_q31.c:153-473 and :524-834) with
+// the same shifts, saturations (__SSAT, Include/dsp/none.h:78-94) and truncating or rounded
+// high-word multiplies (none.h:185-206).  Only the data movement is new: the transform lives in
+// LDS, two radix-4 stages are fused in registers per LDS round trip, and the bit reversal of
+// arm_bitreversal_16/_32 (arm_bitreversal2.c:84-148, plain bit reversal for the fixed tables) is
+// folded into the final, coalesced store.
+#include "armfft_internal.h"
+
+namespace armfft {
+
+// ------------------------------------------------------------------------------------------
+// element types: one complex point
+// ------------------------------------------------------------------------------------------
+struct Q15 {
+  using scalar = int16_t;
+  using word = uint32_t;     // packed {re, im}
+  using tword = uint32_t;    // packed {cos, sin}
+  struct cpx { int16_t re, im; };
+  static __device__ __forceinline__ cpx unpack(word w) { return cpx{(int16_t)(w & 0xffffu), (int16_t)(w >> 16)}; }
+  static __device__ __forceinline__ word pack(cpx c) { return (uint32_t)(uint16_t)c.re | ((uint32_t)(uint16_t)c.im << 16); }
+};
+struct Q31 {
+  using scalar = int32_t;
+  using word = int2;
+  using tword = int2;
+  struct cpx { int32_t re, im; };
+  static __device__ __forceinline__ cpx unpack(word w) { return cpx{w.x, w.y}; }
+  static __device__ __forceinline__ word pack(cpx c) { return make_int2(c.re, c.im); }
+};
+
+__device__ __forceinline__ int ssat16(int v) { return v > 32767 ? 32767 : (v < -32768 ? -32768 : v); }
+__device__ __forceinline__ int32_t wadd(int32_t a, int32_t b) { return (int32_t)((uint32_t)a + (uint32_t)b); }
+__device__ __forceinline__ int32_t wsub(int32_t a, int32_t b) { return (int32_t)((uint32_t)a - (uint32_t)b); }
+__device__ __forceinline__ int32_t wshl1(int32_t a) { return (int32_t)((uint32_t)a << 1); }
+__device__ __forceinline__ int32_t mulhi32(int32_t a, int32_t b) { return __mulhi(a, b); }
+
+// ------------------------------------------------------------------------------------------
+// q15 radix-4 butterflies.  STAGE: 0 = first, 1 = middle, 2 = last.  x[0..3] are the points at
+// i0, i0+n2, i0+2n2, i0+3n2; w1/w2/w3 the twiddles at ic, 2ic, 3ic.  Outputs go back in place:
+// x[1] receives the "c" output (twiddle 2), x[2] the "b" output (twiddle 1), x[3] "d" (twiddle 3).
+// ------------------------------------------------------------------------------------------
+template <int STAGE, bool INV>
+__device__ __forceinline__ void bfly_q15(Q15::cpx *x, Q15::cpx w1, Q15::cpx w2, Q15::cpx w3)
+{
+  int16_t R0, R1, S0, S1, T0, T1, U0, U1, out1, out2;
+  const int16_t Co1 = w1.re, Si1 = w1.im, Co2 = w2.re, Si2 = w2.im, Co3 = w3.re, Si3 = w3.im;
+  if (STAGE == 0) {
+    T0 = x[0].re >> 2; T1 = x[0].im >> 2;
+    S0 = x[2].re >> 2; S1 = x[2].im >> 2;
+  } else {
+    T0 = x[0].re; T1 = x[0].im;
+    S0 = x[2].re; S1 = x[2].im;
+  }
+  R0 = (int16_t)ssat16(T0 + S0); R1 = (int16_t)ssat16(T1 + S1);
+  S0 = (int16_t)ssat16(T0 - S0); S1 = (int16_t)ssat16(T1 - S1);
+  int16_t B0, B1, D0, D1;  // the (scaled) inputs at i1 and i3
+  if (STAGE == 0) {
+    B0 = x[1].re >> 2; B1 = x[1].im >> 2;
+    D0 = x[3].re >> 2; D1 = x[3].im >> 2;
+  } else {
+    B0 = x[1].re; B1 = x[1].im;
+    D0 = x[3].re; D1 = x[3].im;
+  }
+  T0 = (int16_t)ssat16(B0 + D0); T1 = (int16_t)ssat16(B1 + D1);
+  if (STAGE == 1) {
+    x[0].re = (int16_t)(((R0 >> 1) + (T0 >> 1)) >> 1);
+    x[0].im = (int16_t)(((R1 >> 1) + (T1 >> 1)) >> 1);
+  } else {
+    x[0].re = (int16_t)((R0 >> 1) + (T0 >> 1));
+    x[0].im = (int16_t)((R1 >> 1) + (T1 >> 1));
+  }
+  if (STAGE == 0) {
+    R0 = (int16_t)ssat16(R0 - T0); R1 = (int16_t)ssat16(R1 - T1);
+  } else {
+    R0 = (int16_t)((R0 >> 1) - (T0 >> 1)); R1 = (int16_t)((R1 >> 1) - (T1 >> 1));
+  }
+  if (STAGE == 2) {
+    out1 = R0; out2 = R1;
+  } else if (!INV) {
+    out1 = (int16_t)((Co2 * R0 + Si2 * R1) >> 16);
+    out2 = (int16_t)((-Si2 * R0 + Co2 * R1) >> 16);
+  } else {
+    out1 = (int16_t)((Co2 * R0 - Si2 * R1) >> 16);
+    out2 = (int16_t)((Si2 * R0 + Co2 * R1) >> 16);
+  }
+  x[1].re = out1; x[1].im = out2;
+  T0 = (int16_t)ssat16(B0 - D0); T1 = (int16_t)ssat16(B1 - D1);
+  if (STAGE == 0) {
+    if (!INV) {
+      R0 = (int16_t)ssat16((int)S0 - T1); R1 = (int16_t)ssat16((int)S1 + T0);
+      S0 = (int16_t)ssat16((int)S0 + T1); S1 = (int16_t)ssat16((int)S1 - T0);
+    } else {
+      R0 = (int16_t)ssat16((int)S0 + T1); R1 = (int16_t)ssat16((int)S1 - T0);
+      S0 = (int16_t)ssat16((int)S0 - T1); S1 = (int16_t)ssat16((int)S1 + T0);
+    }
+  } else {
+    if (!INV) {
+      R0 = (int16_t)((S0 >> 1) - (T1 >> 1)); R1 = (int16_t)((S1 >> 1) + (T0 >> 1));
+      S0 = (int16_t)((S0 >> 1) + (T1 >> 1)); S1 = (int16_t)((S1 >> 1) - (T0 >> 1));
+    } else {
+      R0 = (int16_t)((S0 >> 1) + (T1 >> 1)); R1 = (int16_t)((S1 >> 1) - (T0 >> 1));
+      S0 = (int16_t)((S0 >> 1) - (T1 >> 1)); S1 = (int16_t)((S1 >> 1) + (T0 >> 1));
+    }
+  }
+  if (STAGE == 2) {
+    x[2].re = S0; x[2].im = S1;
+    x[3].re = R0; x[3].im = R1;
+  } else if (!INV) {
+    x[2].re = (int16_t)((Co1 * S0 + Si1 * S1) >> 16);
+    x[2].im = (int16_t)((-Si1 * S0 + Co1 * S1) >> 16);
+    x[3].re = (int16_t)((Si3 * R1 + Co3 * R0) >> 16);
+    x[3].im = (int16_t)((-Si3 * R0 + Co3 * R1) >> 16);
+  } else {
+    x[2].re = (int16_t)((Co1 * S0 - Si1 * S1) >> 16);
+    x[2].im = (int16_t)((Si1 * S0 + Co1 * S1) >> 16);
+    x[3].re = (int16_t)((Co3 * R0 - Si3 * R1) >> 16);
+    x[3].im = (int16_t)((Si3 * R0 + Co3 * R1) >> 16);
+  }
+}
+
+// radix-2 pre-stage of arm_cfft_radix4by2[_inverse]_q15 (arm_cfft_q15.c:786-804, :885-903)
+template <bool INV>
+__device__ __forceinline__ void by2_q15(Q15::cpx &a, Q15::cpx &b, Q15::cpx w)
+{
+  const int16_t c = w.re, s = w.im;
+  int16_t xt = (int16_t)((a.re >> 1) - (b.re >> 1));
+  a.re = (int16_t)(((a.re >> 1) + (b.re >> 1)) >> 1);
+  int16_t yt = (int16_t)((a.im >> 1) - (b.im >> 1));
+  a.im = (int16_t)(((b.im >> 1) + (a.im >> 1)) >> 1);
+  if (!INV) {
+    b.re = (int16_t)(((int16_t)(((int)xt * c) >> 16)) + ((int16_t)(((int)yt * s) >> 16)));
+    b.im = (int16_t)(((int16_t)(((int)yt * c) >> 16)) - ((int16_t)(((int)xt * s) >> 16)));
+  } else {
+    b.re = (int16_t)(((int16_t)(((int)xt * c) >> 16)) - ((int16_t)(((int)yt * s) >> 16)));
+    b.im = (int16_t)(((int16_t)(((int)yt * c) >> 16)) + ((int16_t)(((int)xt * s) >> 16)));
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// q31 radix-4 butterflies, same conventions
+// ------------------------------------------------------------------------------------------
+template <int STAGE, bool INV>
+__device__ __forceinline__ void bfly_q31(Q31::cpx *x, Q31::cpx w1, Q31::cpx w2, Q31::cpx w3)
+{
+  if (STAGE == 2) {
+    // last stage: plain wrapping adds (arm_cfft_radix4_q31.c:405-464 / :766-826)
+    const int32_t xa = x[0].re, ya = x[0].im, xb = x[1].re, yb = x[1].im, xc = x[2].re, yc = x[2].im, xd = x[3].re, yd = x[3].im;
+    x[0].re = wadd(wadd(wadd(xa, xb), xc), xd);
+    x[0].im = wadd(wadd(wadd(ya, yb), yc), yd);
+    x[1].re = wsub(wadd(wsub(xa, xb), xc), xd);
+    x[1].im = wsub(wadd(wsub(ya, yb), yc), yd);
+    if (!INV) {
+      x[2].re = wsub(wsub(wadd(xa, yb), xc), yd);
+      x[2].im = wadd(wsub(wsub(ya, xb), yc), xd);
+      x[3].re = wadd(wsub(wsub(xa, yb), xc), yd);
+      x[3].im = wsub(wsub(wadd(ya, xb), yc), xd);
+    } else {
+      x[2].re = wadd(wsub(wsub(xa, yb), xc), yd);
+      x[2].im = wsub(wsub(wadd(ya, xb), yc), xd);
+      x[3].re = wsub(wsub(wadd(xa, yb), xc), yd);
+      x[3].im = wadd(wsub(wsub(ya, xb), yc), xd);
+    }
+    return;
+  }
+  int32_t a0r, a0i, a1r, a1i, a2r, a2i, a3r, a3i;
+  if (STAGE == 0) {  // 4 guard bits (arm_cfft_radix4_q31.c:199-227)
+    a0r = x[0].re >> 4; a0i = x[0].im >> 4; a1r = x[1].re >> 4; a1i = x[1].im >> 4;
+    a2r = x[2].re >> 4; a2i = x[2].im >> 4; a3r = x[3].re >> 4; a3i = x[3].im >> 4;
+  } else {
+    a0r = x[0].re; a0i = x[0].im; a1r = x[1].re; a1i = x[1].im;
+    a2r = x[2].re; a2i = x[2].im; a3r = x[3].re; a3i = x[3].im;
+  }
+  int32_t r1 = wadd(a0r, a2r), r2 = wsub(a0r, a2r);
+  int32_t t1 = wadd(a1r, a3r);
+  int32_t s1 = wadd(a0i, a2i), s2 = wsub(a0i, a2i);
+  int32_t t2 = wadd(a1i, a3i);
+  if (STAGE == 0) {
+    x[0].re = wadd(r1, t1);
+    x[0].im = wadd(s1, t2);
+  } else {
+    x[0].re = wadd(r1, t1) >> 2;
+    x[0].im = wadd(s1, t2) >> 2;
+  }
+  r1 = wsub(r1, t1);
+  s1 = wsub(s1, t2);
+  t1 = wsub(a1i, a3i);
+  t2 = wsub(a1r, a3r);
+  int32_t o1r, o1i, o2r, o2i, o3r, o3i;
+  if (!INV) {
+    o1r = wadd(mulhi32(r1, w2.re), mulhi32(s1, w2.im));
+    o1i = wsub(mulhi32(s1, w2.re), mulhi32(r1, w2.im));
+    r1 = wadd(r2, t1); r2 = wsub(r2, t1);
+    s1 = wsub(s2, t2); s2 = wadd(s2, t2);
+    o2r = wadd(mulhi32(r1, w1.re), mulhi32(s1, w1.im));
+    o2i = wsub(mulhi32(s1, w1.re), mulhi32(r1, w1.im));
+    o3r = wadd(mulhi32(r2, w3.re), mulhi32(s2, w3.im));
+    o3i = wsub(mulhi32(s2, w3.re), mulhi32(r2, w3.im));
+  } else {
+    o1r = wsub(mulhi32(r1, w2.re), mulhi32(s1, w2.im));
+    o1i = wadd(mulhi32(s1, w2.re), mulhi32(r1, w2.im));
+    r1 = wsub(r2, t1); r2 = wadd(r2, t1);
+    s1 = wadd(s2, t2); s2 = wsub(s2, t2);
+    o2r = wsub(mulhi32(r1, w1.re), mulhi32(s1, w1.im));
+    o2i = wadd(mulhi32(s1, w1.re), mulhi32(r1, w1.im));
+    o3r = wsub(mulhi32(r2, w3.re), mulhi32(s2, w3.im));
+    o3i = wadd(mulhi32(s2, w3.re), mulhi32(r2, w3.im));
+  }
+  if (STAGE == 0) {
+    x[1].re = wshl1(o1r); x[1].im = wshl1(o1i);
+    x[2].re = wshl1(o2r); x[2].im = wshl1(o2i);
+    x[3].re = wshl1(o3r); x[3].im = wshl1(o3i);
+  } else {
+    x[1].re = o1r >> 1; x[1].im = o1i >> 1;
+    x[2].re = o2r >> 1; x[2].im = o2i >> 1;
+    x[3].re = o3r >> 1; x[3].im = o3i >> 1;
+  }
+}
+
+// arm_cfft_radix4by2[_inverse]_q31 pre-stage (arm_cfft_q31.c:778-798, :839-859): SMMULR/SMMLAR/SMMLSR
+template <bool INV>
+__device__ __forceinline__ void by2_q31(Q31::cpx &a, Q31::cpx &b, Q31::cpx w)
+{
+  const int32_t c = w.re, s = w.im;
+  int32_t xt = wsub(a.re >> 2, b.re >> 2);
+  a.re = wadd(a.re >> 2, b.re >> 2);
+  int32_t yt = wsub(a.im >> 2, b.im >> 2);
+  a.im = wadd(b.im >> 2, a.im >> 2);
+  long long p0 = ((long long)xt * c + 0x80000000LL) >> 32;
+  long long p1 = ((long long)yt * c + 0x80000000LL) >> 32;
+  int32_t q0 = (int32_t)p0, q1 = (int32_t)p1;
+  if (!INV) {
+    q0 = (int32_t)(((long long)((unsigned long long)(long long)q0 << 32) + (long long)yt * s + 0x80000000LL) >> 32);
+    q1 = (int32_t)(((long long)((unsigned long long)(long long)q1 << 32) - (long long)xt * s + 0x80000000LL) >> 32);
+  } else {
+    q0 = (int32_t)(((long long)((unsigned long long)(long long)q0 << 32) - (long long)yt * s + 0x80000000LL) >> 32);
+    q1 = (int32_t)(((long long)((unsigned long long)(long long)q1 << 32) + (long long)xt * s + 0x80000000LL) >> 32);
+  }
+  b.re = wshl1(q0);
+  b.im = wshl1(q1);
+}
+
+// dispatch by element type
+template <class Q, int STAGE, bool INV>
+__device__ __forceinline__ void bfly(typename Q::cpx *x, typename Q::cpx w1, typename Q::cpx w2, typename Q::cpx w3)
+{
+  if constexpr (sizeof(typename Q::scalar) == 2)
+    bfly_q15<STAGE, INV>(x, w1, w2, w3);
+  else
+    bfly_q31<STAGE, INV>(x, w1, w2, w3);
+}
+template <class Q, bool INV>
+__device__ __forceinline__ void by2(typename Q::cpx &a, typename Q::cpx &b, typename Q::cpx w)
+{
+  if constexpr (sizeof(typename Q::scalar) == 2)
+    by2_q15<INV>(a, b, w);
+  else
+    by2_q31<INV>(a, b, w);
+}
+template <class Q>
+__device__ __forceinline__ typename Q::cpx shl1(typename Q::cpx v)
+{
+  if constexpr (sizeof(typename Q::scalar) == 2)
+    return typename Q::cpx{(int16_t)((uint16_t)v.re << 1), (int16_t)((uint16_t)v.im << 1)};
+  else
+    return typename Q::cpx{wshl1(v.re), wshl1(v.im)};
+}
+
+// ------------------------------------------------------------------------------------------
+// plan: N = 2^LOGN, optional radix-2 pre-stage, sub-transform L = 4^M
+// ------------------------------------------------------------------------------------------
+template <int LOGN>
+struct FixedPlan {
+  static constexpr int N = 1 << LOGN;
+  static constexpr bool BY2 = (LOGN & 1) != 0;
+  static constexpr int LOGL = BY2 ? LOGN - 1 : LOGN;
+  static constexpr int L = 1 << LOGL;
+  static constexpr int M = LOGL / 2;             // radix-4 stages
+  static constexpr int T = (N >= 4096) ? N / 16 : 256;
+  static constexpr int TPB = (T * 16) / N;
+  static constexpr int ELEMS = TPB * N;
+  static constexpr int LDS_WORDS = ELEMS + (ELEMS >> 4);  // pad one point per 16
+};
+
+__device__ __forceinline__ int fpad(int e) { return e + (e >> 4); }
+
+// stage class of radix-4 stage s of M: 0 first, 2 last, 1 middle
+template <int S, int M>
+struct StageKind { static constexpr int value = (S == 0) ? 0 : ((S == M - 1) ? 2 : 1); };
+
+// One fused step over the 16 points of a thread.  S = first stage of the step, PAIR = two stages
+// (S, S+1) or one.  r = group index inside the sub-transform (0 .. L/16-1), base = first point of
+// the sub-transform in LDS, tw = table of the FULL transform (3N/4 entries), TWMOD0 = 1 or 2
+// (arm_cfft_radix4by2 calls the butterflies with twidCoefModifier 2).
+template <class Q, int LOGL, int S, bool PAIR, bool INV, int TWMOD0>
+__device__ __forceinline__ void fused_step(typename Q::word *lds, const typename Q::tword *__restrict__ tw, int base, int r)
+{
+  using cpx = typename Q::cpx;
+  constexpr int M = LOGL / 2;
+  constexpr int LOGN1 = LOGL - 2 * S;       // log2 n1 of stage S
+  cpx x[16];
+  if (PAIR) {
+    constexpr int LOGQ = LOGN1 - 4;          // q = n1/16
+    const int blk = r >> LOGQ, j = r & ((1 << LOGQ) - 1);
+    const int e0 = base + (blk << LOGN1) + j;
+#pragma unroll
+    for (int c = 0; c < 16; c++) x[c] = Q::unpack(lds[fpad(e0 + (c << LOGQ))]);
+    // stage S: for each b, butterfly over a (points c = 4a + b); twiddle index jj = j + b*q
+    constexpr int MOD_S = TWMOD0 << (2 * S);
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+      cpx y[4] = {x[b], x[4 + b], x[8 + b], x[12 + b]};
+      const int ic = (j + (b << LOGQ)) * MOD_S;
+      cpx w1{}, w2{}, w3{};
+      if (StageKind<S, M>::value != 2) {
+        w1 = Q::unpack(tw[ic]);
+        w2 = Q::unpack(tw[2 * ic]);
+        w3 = Q::unpack(tw[3 * ic]);
+      }
+      bfly<Q, StageKind<S, M>::value, INV>(y, w1, w2, w3);
+      x[b] = y[0]; x[4 + b] = y[1]; x[8 + b] = y[2]; x[12 + b] = y[3];
+    }
+    // stage S+1: for each a, butterfly over b (points 4a + b); twiddle index j
+    constexpr int MOD_S1 = TWMOD0 << (2 * (S + 1));
+    cpx w1{}, w2{}, w3{};
+    if (StageKind<S + 1, M>::value != 2) {
+      const int ic = j * MOD_S1;
+      w1 = Q::unpack(tw[ic]);
+      w2 = Q::unpack(tw[2 * ic]);
+      w3 = Q::unpack(tw[3 * ic]);
+    }
+#pragma unroll
+    for (int a = 0; a < 4; a++) bfly<Q, StageKind<S + 1, M>::value, INV>(&x[4 * a], w1, w2, w3);
+#pragma unroll
+    for (int c = 0; c < 16; c++) lds[fpad(e0 + (c << LOGQ))] = Q::pack(x[c]);
+  } else {
+    // single stage: 4 independent butterflies u = r + k*(L/16), k = 0..3
+    constexpr int LOGN2 = LOGN1 - 2;
+    constexpr int MOD_S = TWMOD0 << (2 * S);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int u = r + (k << (LOGL - 4));
+      const int blk = u >> LOGN2, j = u & ((1 << LOGN2) - 1);
+      const int e0 = base + (blk << LOGN1) + j;
+      cpx y[4];
+#pragma unroll
+      for (int a = 0; a < 4; a++) y[a] = Q::unpack(lds[fpad(e0 + (a << LOGN2))]);
+      cpx w1{}, w2{}, w3{};
+      if (StageKind<S, M>::value != 2) {
+        const int ic = j * MOD_S;
+        w1 = Q::unpack(tw[ic]);
+        w2 = Q::unpack(tw[2 * ic]);
+        w3 = Q::unpack(tw[3 * ic]);
+      }
+      bfly<Q, StageKind<S, M>::value, INV>(y, w1, w2, w3);
+#pragma unroll
+      for (int a = 0; a < 4; a++) lds[fpad(e0 + (a << LOGN2))] = Q::pack(y[a]);
+    }
+  }
+}
+
+// all radix-4 stages from S on: a single stage first when the count is odd, then pairs
+template <class Q, int LOGL, int S, bool INV, int TWMOD0>
+__device__ __forceinline__ void run_stages(typename Q::word *lds, const typename Q::tword *__restrict__ tw, int base, int r)
+{
+  constexpr int M = LOGL / 2;
+  if constexpr (S < M) {
+    constexpr bool PAIR = ((M - S) % 2) == 0;
+    fused_step<Q, LOGL, S, PAIR, INV, TWMOD0>(lds, tw, base, r);
+    __syncthreads();
+    run_stages<Q, LOGL, S + (PAIR ? 2 : 1), INV, TWMOD0>(lds, tw, base, r);
+  }
+}
+
+template <class Q, int LOGN, bool INV>
+__global__ __launch_bounds__(FixedPlan<LOGN>::T, 4) void cfft_fixed_kernel(typename Q::word *__restrict__ data,
+                                                                          const typename Q::tword *__restrict__ tw, uint32_t batch,
+                                                                          uint32_t ngroups, int bitrev)
+{
+  using PL = FixedPlan<LOGN>;
+  using word = typename Q::word;
+  using cpx = typename Q::cpx;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  word *lds = reinterpret_cast<word *>(lds_raw);
+  const int tid = threadIdx.x;
+  const uint32_t g = blockIdx.x + blockIdx.y * gridDim.x;
+  if (g >= ngroups) return;
+  const size_t gbase = (size_t)g * PL::ELEMS;  // first point of this workgroup's transforms
+  const uint32_t nvalid = (batch - g * PL::TPB) >= (uint32_t)PL::TPB ? (uint32_t)PL::ELEMS : (batch - g * PL::TPB) * PL::N;
+
+  // ---- global -> LDS, 16 bytes per lane ----
+  constexpr int PER16 = 16 / sizeof(word);  // points per 16-byte access
+  for (int v = tid; v < PL::ELEMS / PER16; v += PL::T) {
+    const int e = v * PER16;
+    if ((uint32_t)e < nvalid) {
+      const uint4 raw = *reinterpret_cast<const uint4 *>(data + gbase + e);
+      const word *pw = reinterpret_cast<const word *>(&raw);
+#pragma unroll
+      for (int k = 0; k < PER16; k++) lds[fpad(e + k)] = pw[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < PER16; k++) lds[fpad(e + k)] = word{};
+    }
+  }
+  __syncthreads();
+
+  // ---- radix-2 pre-stage for N = 2 * 4^k ----
+  if constexpr (PL::BY2) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int u = tid + k * PL::T;                 // pair index over the workgroup
+      const int t = u >> (LOGN - 1), i = u & (PL::L - 1);
+      const int ea = t * PL::N + i, eb = ea + PL::L;
+      cpx a = Q::unpack(lds[fpad(ea)]), b = Q::unpack(lds[fpad(eb)]);
+      by2<Q, INV>(a, b, Q::unpack(tw[i]));
+      lds[fpad(ea)] = Q::pack(a);
+      lds[fpad(eb)] = Q::pack(b);
+    }
+    __syncthreads();
+  }
+
+  // ---- radix-4 stages on each sub-transform of length L ----
+  {
+    const int sub = tid >> (PL::LOGL - 4), r = tid & ((PL::L >> 4) - 1);
+    run_stages<Q, PL::LOGL, 0, INV, PL::BY2 ? 2 : 1>(lds, tw, sub * PL::L, r);
+  }
+
+  // ---- LDS -> global, bit reversal (over all LOGN bits) folded into the read, 16 B per lane ----
+  for (int v = tid; v < PL::ELEMS / PER16; v += PL::T) {
+    const int e = v * PER16;
+    if ((uint32_t)e >= nvalid) continue;
+    uint4 raw;
+    word *pw = reinterpret_cast<word *>(&raw);
+#pragma unroll
+    for (int k = 0; k < PER16; k++) {
+      const int idx = e + k, t = idx >> LOGN, i = idx & (PL::N - 1);
+      const int src = bitrev ? (int)(__brev((unsigned)i) >> (32 - LOGN)) : i;
+      cpx c = Q::unpack(lds[fpad(t * PL::N + src)]);
+      if (PL::BY2) c = shl1<Q>(c);  // final << 1 of radix4by2 (arm_cfft_q15.c:814-831, arm_cfft_q31.c:807-824)
+      pw[k] = Q::pack(c);
+    }
+    *reinterpret_cast<uint4 *>(data + gbase + e) = raw;
+  }
+}
+
+// ---- twiddle generation on the device (checked against the host table by the caller) ----
+template <typename T>
+__global__ void gen_twiddle_fixed_kernel(T *tw, uint32_t n, int rounding)
+{
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 3 * n / 4) return;
+  double s, c;
+  if ((4u * i) % n == 0) {
+    const uint32_t q = (4u * i / n) & 3u;
+    c = (q == 0) ? 1.0 : ((q == 2) ? -1.0 : 0.0);
+    s = (q == 1) ? 1.0 : ((q == 3) ? -1.0 : 0.0);
+  } else {
+    sincospi(2.0 * (double)i / (double)n, &s, &c);
+  }
+  const double scale = sizeof(T) == 2 ? 32768.0 : 2147483648.0;
+  const double hi = sizeof(T) == 2 ? 32767.0 : 2147483647.0, lo = -scale;
+  double vc = c * scale, vs = s * scale;
+  vc = rounding ? floor(vc + 0.5) : floor(vc);
+  vs = rounding ? floor(vs + 0.5) : floor(vs);
+  vc = fmin(fmax(vc, lo), hi);
+  vs = fmin(fmax(vs, lo), hi);
+  tw[2 * i] = (T)(long long)vc;
+  tw[2 * i + 1] = (T)(long long)vs;
+}
+
+hipError_t launch_gen_twiddle_q15(int16_t *tw, uint32_t n, int rounding, hipStream_t stream)
+{
+  gen_twiddle_fixed_kernel<int16_t><<<(3 * n / 4 + 255) / 256, 256, 0, stream>>>(tw, n, rounding);
+  return hipGetLastError();
+}
+hipError_t launch_gen_twiddle_q31(int32_t *tw, uint32_t n, int rounding, hipStream_t stream)
+{
+  gen_twiddle_fixed_kernel<int32_t><<<(3 * n / 4 + 255) / 256, 256, 0, stream>>>(tw, n, rounding);
+  return hipGetLastError();
+}
+
+// ---- launchers ----
+template <class Q, int LOGN, bool INV>
+static hipError_t launch_fixed_one(typename Q::word *data, const typename Q::tword *tw, uint32_t batch, bool bitrev, hipStream_t stream)
+{
+  using PL = FixedPlan<LOGN>;
+  constexpr size_t lds_bytes = (size_t)PL::LDS_WORDS * sizeof(typename Q::word);
+  static bool attr_done[16] = {false};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  auto kern = cfft_fixed_kernel<Q, LOGN, INV>;
+  if (lds_bytes > 48 * 1024 && dev < 16 && !attr_done[dev]) {
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+    attr_done[dev] = true;
+  }
+  const uint32_t ngroups = (batch + PL::TPB - 1) / PL::TPB;
+  const uint32_t gx = ngroups < 65536u ? ngroups : 65536u;
+  kern<<<dim3(gx, (ngroups + gx - 1) / gx, 1), PL::T, lds_bytes, stream>>>(data, tw, batch, ngroups, bitrev ? 1 : 0);
+  return hipGetLastError();
+}
+
+template <class Q>
+static hipError_t launch_fixed(int logn, typename Q::word *data, const typename Q::tword *tw, uint32_t batch, bool inverse, bool bitrev,
+                               hipStream_t stream)
+{
+  if (batch == 0) return hipSuccess;
+  switch (logn) {
+#define C(L) \
+  case L: return inverse ? launch_fixed_one<Q, L, true>(data, tw, batch, bitrev, stream) : launch_fixed_one<Q, L, false>(data, tw, batch, bitrev, stream);
+    C(4) C(5) C(6) C(7) C(8) C(9) C(10) C(11) C(12) C(13) C(14)
+#undef C
+  }
+  return hipErrorInvalidValue;
+}
+
+hipError_t launch_cfft_q15(int logn, int16_t *data, const int16_t *tw, uint32_t batch, bool inverse, bool bitrev, hipStream_t stream)
+{
+  return launch_fixed<Q15>(logn, reinterpret_cast<uint32_t *>(data), reinterpret_cast<const uint32_t *>(tw), batch, inverse, bitrev, stream);
+}
+
+hipError_t launch_cfft_q31(int logn, int32_t *data, const int32_t *tw, uint32_t batch, bool inverse, bool bitrev, hipStream_t stream)
+{
+  return launch_fixed<Q31>(logn, reinterpret_cast<int2 *>(data), reinterpret_cast<const int2 *>(tw), batch, inverse, bitrev, stream);
+}
+
+}  // namespace armfft

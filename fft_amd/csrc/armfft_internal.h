@@ -1,0 +1,37 @@
+// armfft_internal.h -- declarations shared by the translation units of libarmfft_mi355.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/arm_fft_mi355.h"
+
+namespace armfft {
+
+constexpr int kMinLog = 4;    // 16
+constexpr int kMaxLog = 14;   // 16384: largest transform held whole in LDS (128 KiB of 160 KiB)
+
+// ---- error plumbing (armfft_abi.cpp) ----
+void set_error(const char *fmt, ...);
+bool hip_ok(hipError_t e, const char *what);
+
+// ---- kernel launchers (no allocation, asynchronous on the stream) ----
+// f32 complex, in place; tw = device table of N entries exp(-2 pi i m / N)
+hipError_t launch_cfft_f32(int logn, float2 *data, const float2 *tw, uint32_t batch, bool inverse, bool scramble,
+                           hipStream_t stream);
+// f32 real: n_real = 2^logn_real points; tw_c = table of the n_real/2-point complex transform,
+// tw_r = n_real/2 entries (sin, cos)(2 pi k / n_real)
+hipError_t launch_rfft_f32(int logn_real, const float *in, float *out, const float2 *tw_c, const float2 *tw_r,
+                           uint32_t batch, bool inverse, hipStream_t stream);
+// fixed point, in place; tw = 3N/4 (cos, sin) pairs
+hipError_t launch_cfft_q15(int logn, int16_t *data, const int16_t *tw, uint32_t batch, bool inverse, bool bitrev,
+                           hipStream_t stream);
+hipError_t launch_cfft_q31(int logn, int32_t *data, const int32_t *tw, uint32_t batch, bool inverse, bool bitrev,
+                           hipStream_t stream);
+
+// on-device table generation
+hipError_t launch_gen_twiddle_f32(float2 *tw, uint32_t n, hipStream_t stream);        // exp(-2 pi i m/n), m < n
+hipError_t launch_gen_twiddle_rfft(float2 *tw, uint32_t n_real, hipStream_t stream);  // (sin, cos)(2 pi k/n_real), k < n_real/2
+hipError_t launch_gen_twiddle_q15(int16_t *tw, uint32_t n, int rounding, hipStream_t stream);
+hipError_t launch_gen_twiddle_q31(int32_t *tw, uint32_t n, int rounding, hipStream_t stream);
+
+}  // namespace armfft

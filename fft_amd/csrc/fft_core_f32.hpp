@@ -1,0 +1,219 @@
+// fft_core_f32.hpp -- LDS-resident Stockham FFT core for gfx950 (device code, header-only).
+//
+// One workgroup of T threads transforms TPB complex sequences of N = 2^LOGN points at once, every
+// thread owning E = 16 points per pass (T * 16 == TPB * N).  The transform is split into
+// ceil(LOGN/4) passes of radix 2/4/8/16; between passes the data crosses the workgroup through
+// LDS (padded against bank conflicts), the first pass reads its inputs through a caller-supplied
+// load functor and the last pass hands its outputs to a store functor, so callers fuse whatever
+// surrounds the FFT (conjugation/scaling, real-FFT split, Doppler wipe-off, spectrum multiply,
+// peak search) without another trip through HBM.  Output is in natural order: the reordering that
+// the reference does with arm_bitreversal_32 (arm_bitreversal2.c:84-108) is folded into the
+// Stockham indexing.  Forward kernel only (e^{-j...}); inverse = conj-in / conj-out like
+// arm_cfft_f32 (arm_cfft_f32.c:1252-1261, :1285-1297), done in the functors.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace armfft {
+
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 w)
+{
+  return make_float2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x);
+}
+__device__ __forceinline__ float2 cmul_conj(float2 a, float2 w)  // a * conj(w)
+{
+  return make_float2(a.x * w.x + a.y * w.y, a.y * w.x - a.x * w.y);
+}
+__device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }   // * (-i)
+
+// ---- in-register butterflies: forward DFT, natural order in and out ----
+__device__ __forceinline__ void fft2(float2 &a, float2 &b)
+{
+  float2 t = a;
+  a = cadd(t, b);
+  b = csub(t, b);
+}
+
+__device__ __forceinline__ void fft4(float2 &a0, float2 &a1, float2 &a2, float2 &a3)
+{
+  float2 t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = mul_mi(csub(a1, a3));
+  a0 = cadd(t0, t2);
+  a1 = cadd(t1, t3);
+  a2 = csub(t0, t2);
+  a3 = csub(t1, t3);
+}
+
+template <int R>
+__device__ __forceinline__ void butterfly(float2 *v);
+
+template <>
+__device__ __forceinline__ void butterfly<2>(float2 *v)
+{
+  fft2(v[0], v[1]);
+}
+
+template <>
+__device__ __forceinline__ void butterfly<4>(float2 *v)
+{
+  fft4(v[0], v[1], v[2], v[3]);
+}
+
+template <>
+__device__ __forceinline__ void butterfly<8>(float2 *v)
+{
+  const float c = 0.70710678118654752440f;
+  fft4(v[0], v[2], v[4], v[6]);  // E0..E3
+  fft4(v[1], v[3], v[5], v[7]);  // O0..O3
+  float2 o1 = make_float2(c * (v[3].x + v[3].y), c * (v[3].y - v[3].x));   // * W8^1
+  float2 o2 = mul_mi(v[5]);                                                // * W8^2
+  float2 o3 = make_float2(c * (v[7].y - v[7].x), -c * (v[7].x + v[7].y));  // * W8^3
+  float2 e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6], o0 = v[1];
+  v[0] = cadd(e0, o0);
+  v[4] = csub(e0, o0);
+  v[1] = cadd(e1, o1);
+  v[5] = csub(e1, o1);
+  v[2] = cadd(e2, o2);
+  v[6] = csub(e2, o2);
+  v[3] = cadd(e3, o3);
+  v[7] = csub(e3, o3);
+}
+
+template <>
+__device__ __forceinline__ void butterfly<16>(float2 *v)
+{
+  // 16 = 4 x 4: X[q1 + 4 q2] = sum_b W16^(b q1) W4^(b q2) sum_a v[4a + b] W4^(a q1)
+  const float c8 = 0.70710678118654752440f;
+  const float c16 = 0.92387953251128675613f, s16 = 0.38268343236508977173f;
+#pragma unroll
+  for (int b = 0; b < 4; b++) fft4(v[b], v[4 + b], v[8 + b], v[12 + b]);  // v[4 q1 + b] = u_b[q1]
+  // twiddle u_b[q1] by W16^(b q1)
+  v[4 * 1 + 1] = cmul(v[4 * 1 + 1], make_float2(c16, -s16));                                             // W16^1
+  v[4 * 1 + 2] = make_float2(c8 * (v[4 * 1 + 2].x + v[4 * 1 + 2].y), c8 * (v[4 * 1 + 2].y - v[4 * 1 + 2].x));  // W16^2
+  v[4 * 1 + 3] = cmul(v[4 * 1 + 3], make_float2(s16, -c16));                                             // W16^3
+  v[4 * 2 + 1] = make_float2(c8 * (v[4 * 2 + 1].x + v[4 * 2 + 1].y), c8 * (v[4 * 2 + 1].y - v[4 * 2 + 1].x));  // W16^2
+  v[4 * 2 + 2] = mul_mi(v[4 * 2 + 2]);                                                                   // W16^4
+  v[4 * 2 + 3] = make_float2(c8 * (v[4 * 2 + 3].y - v[4 * 2 + 3].x), -c8 * (v[4 * 2 + 3].x + v[4 * 2 + 3].y)); // W16^6
+  v[4 * 3 + 1] = cmul(v[4 * 3 + 1], make_float2(s16, -c16));                                             // W16^3
+  v[4 * 3 + 2] = make_float2(c8 * (v[4 * 3 + 2].y - v[4 * 3 + 2].x), -c8 * (v[4 * 3 + 2].x + v[4 * 3 + 2].y)); // W16^6
+  v[4 * 3 + 3] = cmul(v[4 * 3 + 3], make_float2(-c16, s16));                                             // W16^9
+  // second layer over b; result X[q1 + 4 q2] lands in v[4 q1 + q2] -> transpose to natural order
+#pragma unroll
+  for (int q1 = 0; q1 < 4; q1++) fft4(v[4 * q1 + 0], v[4 * q1 + 1], v[4 * q1 + 2], v[4 * q1 + 3]);
+  float2 t;
+#define ARMFFT_SWAP(i, j) t = v[i]; v[i] = v[j]; v[j] = t;
+  ARMFFT_SWAP(1, 4) ARMFFT_SWAP(2, 8) ARMFFT_SWAP(3, 12) ARMFFT_SWAP(6, 9) ARMFFT_SWAP(7, 13) ARMFFT_SWAP(11, 14)
+#undef ARMFFT_SWAP
+}
+
+// ---- compile-time plan ----
+template <int LOGN>
+struct Plan {
+  static constexpr int N = 1 << LOGN;
+  static constexpr int NPASS = (LOGN + 3) / 4;
+  static constexpr int BASE = LOGN / NPASS;
+  static constexpr int EXTRA = LOGN % NPASS;
+  // log2 radix of pass p: the first EXTRA passes are one bit wider
+  static constexpr int lr(int p) { return BASE + (p < EXTRA ? 1 : 0); }
+  // log2 of Ns (product of the radices of the passes before p)
+  static constexpr int lns(int p) { return p == 0 ? 0 : lns(p - 1) + lr(p - 1); }
+  // threads per workgroup and transforms per workgroup at 16 points per thread
+  static constexpr int T = (N >= 4096) ? N / 16 : 256;
+  static constexpr int TPB = (T * 16) / N;
+  static constexpr int LDS_ELEMS = TPB * N + ((TPB * N) >> 4) * 2;  // pad 2 complex per 16
+  static constexpr size_t LDS_BYTES = (size_t)LDS_ELEMS * sizeof(float2);
+};
+
+__device__ __forceinline__ int lds_pad(int e) { return e + ((e >> 4) << 1); }
+
+// One pass.  P = pass index.  v holds the thread's 16 points: butterfly q (0..16/R-1), leg r at
+// v[q*R + r].
+template <int LOGN, int P, bool LDS_IN, bool LDS_OUT, class Load, class Store>
+__device__ __forceinline__ void fft_pass(float2 *v, float2 *lds, const float2 *__restrict__ tw, int tid, Load &ld, Store &st)
+{
+  using PL = Plan<LOGN>;
+  constexpr int N = PL::N, T = PL::T;
+  constexpr int LR = PL::lr(P), R = 1 << LR, NB = 16 / R;
+  constexpr int LNS = PL::lns(P), NS = 1 << LNS;
+  constexpr int LNR = LOGN - LR;  // log2(N/R): butterflies per transform
+  constexpr bool FIRST = (P == 0), LAST = (P == PL::NPASS - 1);
+
+  // ---- gather ----
+#pragma unroll
+  for (int q = 0; q < NB; q++) {
+    const int w = tid + q * T;
+    const int t = w >> LNR, j = w & ((1 << LNR) - 1);
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      const int e = j + (r << LNR);
+      if (FIRST)
+        v[q * R + r] = ld(t, e);
+      else
+        v[q * R + r] = lds[lds_pad(t * N + e)];
+    }
+  }
+  // ---- twiddle + butterfly ----
+#pragma unroll
+  for (int q = 0; q < NB; q++) {
+    const int w = tid + q * T;
+    const int j = w & ((1 << LNR) - 1);
+    if (!FIRST) {
+      const int k = j & (NS - 1);
+      // W_{NS*R}^{r k} = tw[r * k * N/(NS*R)]
+      const int stepk = k << (LOGN - LNS - LR);
+#pragma unroll
+      for (int r = 1; r < R; r++) v[q * R + r] = cmul(v[q * R + r], tw[r * stepk]);
+    }
+    butterfly<R>(v + q * R);
+  }
+  // ---- scatter ----
+  // source and destination both in LDS: every read of this pass must finish before any write
+  if ((!FIRST || LDS_IN) && (!LAST || LDS_OUT)) __syncthreads();
+#pragma unroll
+  for (int q = 0; q < NB; q++) {
+    const int w = tid + q * T;
+    const int t = w >> LNR, j = w & ((1 << LNR) - 1);
+    const int k = j & (NS - 1);
+    const int j0 = ((j >> LNS) << (LNS + LR)) + k;
+    if (LAST) {
+#pragma unroll
+      for (int r = 0; r < R; r++) st(t, j0 + (r << LNS), v[q * R + r]);
+    } else if (FIRST && R >= 2) {
+      // NS == 1: R consecutive points per butterfly -> 16-byte LDS stores
+#pragma unroll
+      for (int r = 0; r < R; r += 2) {
+        const int e = t * N + j * R + r;
+        *reinterpret_cast<float4 *>(&lds[lds_pad(e)]) = make_float4(v[q * R + r].x, v[q * R + r].y, v[q * R + r + 1].x, v[q * R + r + 1].y);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < R; r++) lds[lds_pad(t * N + j0 + (r << LNS))] = v[q * R + r];
+    }
+  }
+  if (!LAST) __syncthreads();
+}
+
+template <int LOGN, int P, bool LDS_IN, bool LDS_OUT, class Load, class Store>
+struct PassLoop {
+  static __device__ __forceinline__ void run(float2 *v, float2 *lds, const float2 *__restrict__ tw, int tid, Load &ld, Store &st)
+  {
+    fft_pass<LOGN, P, LDS_IN, LDS_OUT>(v, lds, tw, tid, ld, st);
+    if constexpr (P + 1 < Plan<LOGN>::NPASS) PassLoop<LOGN, P + 1, LDS_IN, LDS_OUT, Load, Store>::run(v, lds, tw, tid, ld, st);
+  }
+};
+
+// Transform the workgroup's TPB sequences.  ld(t, e) returns point e of sequence t (t < TPB),
+// st(t, e, val) receives output bin e of sequence t.  `lds` must hold Plan<LOGN>::LDS_ELEMS float2
+// (16-byte aligned) and must not be in use by other threads when the call starts; on return all
+// st() calls of this thread have been issued (no trailing barrier).  LDS_IN / LDS_OUT: set when
+// ld() reads / st() writes the workgroup's LDS (anywhere), so that the core separates them from
+// its own LDS traffic with a barrier.
+template <int LOGN, bool LDS_IN, bool LDS_OUT, class Load, class Store>
+__device__ __forceinline__ void fft_block(float2 *lds, const float2 *__restrict__ tw, int tid, Load ld, Store st)
+{
+  float2 v[16];
+  PassLoop<LOGN, 0, LDS_IN, LDS_OUT, Load, Store>::run(v, lds, tw, tid, ld, st);
+}
+
+}  // namespace armfft

@@ -1,0 +1,190 @@
+/*
+ * arm_fft_mi355.h -- C ABI of libarmfft_mi355.so: the CMSIS-DSP transform hot path of
+ * fy10000000/FFT, re-implemented as hand-written HIP kernels for AMD MI355X (gfx950).
+ *
+ * Drop-in surface: the structs and the init/execute functions below keep the names, layouts,
+ * argument meaning and error behaviour of the reference's non-Neon/non-MVE C API
+ * (reference file:line cited per declaration, paths relative to the reference root), so an
+ * existing caller (CMSIS/CMSIS.cpp, the Testing/ suites) relinks unchanged.  Extensions
+ * (suffixes _batch, _dev, prefix gnss_/arm_fft_mi355_) are new and return arm_status.
+ *
+ * Conventions
+ *   - complex data is interleaved {re, im}; transform b of a batch starts at p + 2*fftLen*b
+ *     (rfft: p + fftLenRFFT*b, pOut + fftLenRFFT*b);
+ *   - host-pointer entry points copy in and out synchronously; *_dev entry points take device
+ *     pointers and a hipStream_t (as void*), launch asynchronously and never allocate;
+ *   - instances are caller-owned PODs; pTwiddle / pBitRevTable point to valid HOST tables owned
+ *     by the library (static lifetime), device plans are cached inside the library per GPU.
+ */
+#ifndef ARM_FFT_MI355_H
+#define ARM_FFT_MI355_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- scalar types and status: Include/arm_math_types.h:334-350, :610-617 ---- */
+typedef int16_t q15_t;
+typedef int32_t q31_t;
+typedef int64_t q63_t;
+typedef float float32_t;
+
+typedef enum {
+  ARM_MATH_SUCCESS = 0,
+  ARM_MATH_ARGUMENT_ERROR = -1,
+  ARM_MATH_LENGTH_ERROR = -2,
+  ARM_MATH_SIZE_MISMATCH = -3,
+  ARM_MATH_NANINF = -4,
+  ARM_MATH_SINGULAR = -5,
+  ARM_MATH_TEST_FAILURE = -6,
+  ARM_MATH_DECOMPOSITION_FAILURE = -7
+} arm_status;
+
+/* ---- instance structures ---- */
+/* Include/dsp/transform_functions.h:416-430 */
+typedef struct {
+  uint16_t fftLen;
+  const float32_t *pTwiddle;
+  const uint16_t *pBitRevTable;
+  uint16_t bitRevLength;
+} arm_cfft_instance_f32;
+
+/* Include/dsp/transform_functions.h:284-298 */
+typedef struct {
+  uint16_t fftLen;
+  const q15_t *pTwiddle;
+  const uint16_t *pBitRevTable;
+  uint16_t bitRevLength;
+} arm_cfft_instance_q15;
+
+/* Include/dsp/transform_functions.h:352-366 */
+typedef struct {
+  uint16_t fftLen;
+  const q31_t *pTwiddle;
+  const uint16_t *pBitRevTable;
+  uint16_t bitRevLength;
+} arm_cfft_instance_q31;
+
+/* Include/dsp/transform_functions.h:827-832 */
+typedef struct {
+  arm_cfft_instance_f32 Sint;
+  uint16_t fftLenRFFT;
+  const float32_t *pTwiddleRFFT;
+} arm_rfft_fast_instance_f32;
+
+/* ---- f32 complex FFT ---- */
+/* Include/dsp/transform_functions.h:433-445; bodies Source/TransformFunctions/arm_cfft_init_f32.c:121-354.
+ * Unsupported length -> ARM_MATH_ARGUMENT_ERROR.  Extension: 8192 and 16384 are accepted too
+ * (the fork's stated goal, CMSIS/CMSIS.cpp:1-10; the reference stops at 4096). */
+arm_status arm_cfft_init_4096_f32(arm_cfft_instance_f32 *S);
+arm_status arm_cfft_init_2048_f32(arm_cfft_instance_f32 *S);
+arm_status arm_cfft_init_1024_f32(arm_cfft_instance_f32 *S);
+arm_status arm_cfft_init_512_f32(arm_cfft_instance_f32 *S);
+arm_status arm_cfft_init_256_f32(arm_cfft_instance_f32 *S);
+arm_status arm_cfft_init_128_f32(arm_cfft_instance_f32 *S);
+arm_status arm_cfft_init_64_f32(arm_cfft_instance_f32 *S);
+arm_status arm_cfft_init_32_f32(arm_cfft_instance_f32 *S);
+arm_status arm_cfft_init_16_f32(arm_cfft_instance_f32 *S);
+arm_status arm_cfft_init_f32(arm_cfft_instance_f32 *S, uint16_t fftLen);
+
+/* Include/dsp/transform_functions.h:461-465; body arm_cfft_f32.c:1243-1298.  In place, forward
+ * unscaled, inverse scaled by 1/fftLen; bitReverseFlag 1 = natural order (0 = the reference's
+ * digit-scrambled order).  Silently does nothing for an unsupported fftLen, like the reference's
+ * switch without default (:1263-1280); GPU failures are reported by arm_fft_mi355_last_error(). */
+void arm_cfft_f32(const arm_cfft_instance_f32 *S, float32_t *p1, uint8_t ifftFlag, uint8_t bitReverseFlag);
+
+/* extension: `batch` transforms back to back, host pointers */
+arm_status arm_cfft_batch_f32(const arm_cfft_instance_f32 *S, float32_t *p1, uint32_t batch, uint8_t ifftFlag,
+                              uint8_t bitReverseFlag);
+/* extension: device pointers, asynchronous on `stream` (hipStream_t), no allocation */
+arm_status arm_cfft_f32_dev(const arm_cfft_instance_f32 *S, float32_t *p1_dev, uint32_t batch, uint8_t ifftFlag,
+                            uint8_t bitReverseFlag, void *stream);
+
+/* ---- q15 complex FFT ---- */
+/* Include/dsp/transform_functions.h:302-316; bodies arm_cfft_init_q15.c:117-352 (16..4096).
+ * 8192 is accepted (declared by the fork at :303 but never defined); 16384 likewise. */
+arm_status arm_cfft_init_16384_q15(arm_cfft_instance_q15 *S);
+arm_status arm_cfft_init_8192_q15(arm_cfft_instance_q15 *S);
+arm_status arm_cfft_init_4096_q15(arm_cfft_instance_q15 *S);
+arm_status arm_cfft_init_2048_q15(arm_cfft_instance_q15 *S);
+arm_status arm_cfft_init_1024_q15(arm_cfft_instance_q15 *S);
+arm_status arm_cfft_init_512_q15(arm_cfft_instance_q15 *S);
+arm_status arm_cfft_init_256_q15(arm_cfft_instance_q15 *S);
+arm_status arm_cfft_init_128_q15(arm_cfft_instance_q15 *S);
+arm_status arm_cfft_init_64_q15(arm_cfft_instance_q15 *S);
+arm_status arm_cfft_init_32_q15(arm_cfft_instance_q15 *S);
+arm_status arm_cfft_init_16_q15(arm_cfft_instance_q15 *S);
+arm_status arm_cfft_init_q15(arm_cfft_instance_q15 *S, uint16_t fftLen);
+/* Include/dsp/transform_functions.h:332-336; body arm_cfft_q15.c:671-726 (+ radix4by2 :736-931,
+ * butterflies arm_cfft_radix4_q15.c:572-970, :1434-1813).  Output down-scaled by fftLen with the
+ * per-stage shifts and saturations of the reference's generic-C branch reproduced bit for bit. */
+void arm_cfft_q15(const arm_cfft_instance_q15 *S, q15_t *p1, uint8_t ifftFlag, uint8_t bitReverseFlag);
+arm_status arm_cfft_batch_q15(const arm_cfft_instance_q15 *S, q15_t *p1, uint32_t batch, uint8_t ifftFlag,
+                              uint8_t bitReverseFlag);
+arm_status arm_cfft_q15_dev(const arm_cfft_instance_q15 *S, q15_t *p1_dev, uint32_t batch, uint8_t ifftFlag,
+                            uint8_t bitReverseFlag, void *stream);
+
+/* ---- q31 complex FFT ---- */
+/* Include/dsp/transform_functions.h:369-382; bodies arm_cfft_init_q31.c:118-355 (16..4096).
+ * Extension: 8192 and 16384 (same butterflies, the fork's larger tables). */
+arm_status arm_cfft_init_8192_q31(arm_cfft_instance_q31 *S);
+arm_status arm_cfft_init_4096_q31(arm_cfft_instance_q31 *S);
+arm_status arm_cfft_init_2048_q31(arm_cfft_instance_q31 *S);
+arm_status arm_cfft_init_1024_q31(arm_cfft_instance_q31 *S);
+arm_status arm_cfft_init_512_q31(arm_cfft_instance_q31 *S);
+arm_status arm_cfft_init_256_q31(arm_cfft_instance_q31 *S);
+arm_status arm_cfft_init_128_q31(arm_cfft_instance_q31 *S);
+arm_status arm_cfft_init_64_q31(arm_cfft_instance_q31 *S);
+arm_status arm_cfft_init_32_q31(arm_cfft_instance_q31 *S);
+arm_status arm_cfft_init_16_q31(arm_cfft_instance_q31 *S);
+arm_status arm_cfft_init_q31(arm_cfft_instance_q31 *S, uint16_t fftLen);
+/* Include/dsp/transform_functions.h:396-400; body arm_cfft_q31.c:708-759 (+ radix4by2 :767-885,
+ * butterflies arm_cfft_radix4_q31.c:153-473, :524-834, multiplies Include/dsp/none.h:185-206). */
+void arm_cfft_q31(const arm_cfft_instance_q31 *S, q31_t *p1, uint8_t ifftFlag, uint8_t bitReverseFlag);
+arm_status arm_cfft_batch_q31(const arm_cfft_instance_q31 *S, q31_t *p1, uint32_t batch, uint8_t ifftFlag,
+                              uint8_t bitReverseFlag);
+arm_status arm_cfft_q31_dev(const arm_cfft_instance_q31 *S, q31_t *p1_dev, uint32_t batch, uint8_t ifftFlag,
+                            uint8_t bitReverseFlag, void *stream);
+
+/* ---- f32 real FFT ---- */
+/* Include/dsp/transform_functions.h:834-847; bodies arm_rfft_fast_init_f32.c:83-383 (32..4096).
+ * Extension: 8192 and 16384 real points (needs the 4096/8192-point complex transform). */
+arm_status arm_rfft_fast_init_32_f32(arm_rfft_fast_instance_f32 *S);
+arm_status arm_rfft_fast_init_64_f32(arm_rfft_fast_instance_f32 *S);
+arm_status arm_rfft_fast_init_128_f32(arm_rfft_fast_instance_f32 *S);
+arm_status arm_rfft_fast_init_256_f32(arm_rfft_fast_instance_f32 *S);
+arm_status arm_rfft_fast_init_512_f32(arm_rfft_fast_instance_f32 *S);
+arm_status arm_rfft_fast_init_1024_f32(arm_rfft_fast_instance_f32 *S);
+arm_status arm_rfft_fast_init_2048_f32(arm_rfft_fast_instance_f32 *S);
+arm_status arm_rfft_fast_init_4096_f32(arm_rfft_fast_instance_f32 *S);
+arm_status arm_rfft_fast_init_f32(arm_rfft_fast_instance_f32 *S, uint16_t fftLen);
+/* Include/dsp/transform_functions.h:860-863; body arm_rfft_fast_f32.c:675-699 (stage :316-402,
+ * merge :405-462).  Forward: fftLenRFFT reals -> {DC, Nyquist, X1..X(N/2-1)}; inverse the reverse.
+ * The reference clobbers `p` in the forward direction; here `p` is left untouched. */
+void arm_rfft_fast_f32(const arm_rfft_fast_instance_f32 *S, float32_t *p, float32_t *pOut, uint8_t ifftFlag);
+arm_status arm_rfft_fast_batch_f32(const arm_rfft_fast_instance_f32 *S, float32_t *p, float32_t *pOut,
+                                   uint32_t batch, uint8_t ifftFlag);
+arm_status arm_rfft_fast_f32_dev(const arm_rfft_fast_instance_f32 *S, const float32_t *p_dev, float32_t *pOut_dev,
+                                 uint32_t batch, uint8_t ifftFlag, void *stream);
+
+/* ---- library services (no counterpart in the reference) ---- */
+/* Select the GPU used by the calling thread's host-pointer entry points and build nothing else;
+ * optional (device 0 / the current HIP device is used otherwise). */
+arm_status arm_fft_mi355_set_device(int device);
+/* Pre-build the device plan (on-device twiddle generation) for one size so that the first timed
+ * call does not pay for it: kind 0 = f32, 1 = q15, 2 = q31, 3 = rfft f32. */
+arm_status arm_fft_mi355_warm(int kind, uint32_t fftLen);
+/* Message of the last failure on the calling thread ("" if none). */
+const char *arm_fft_mi355_last_error(void);
+/* Rounding rule of the fixed-point twiddle tables: 0 = floor (default), 1 = nearest.  Must be
+ * set before the first q15/q31 init; see DESIGN.md "fixed-point twiddles". */
+arm_status arm_fft_mi355_set_twiddle_rounding(int mode);
+const char *arm_fft_mi355_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ARM_FFT_MI355_H */

@@ -1,0 +1,138 @@
+"""Shared test helpers: oracle loader (ctypes), golden fixtures, reference-style assertions."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+c_f = ctypes.POINTER(ctypes.c_float)
+c_d = ctypes.POINTER(ctypes.c_double)
+c_i16 = ctypes.POINTER(ctypes.c_int16)
+c_i32 = ctypes.POINTER(ctypes.c_int32)
+c_u32 = ctypes.POINTER(ctypes.c_uint32)
+
+
+def ptr(a, t):
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(t)
+
+
+class OrcC32(ctypes.Structure):
+    _fields_ = [("r", ctypes.c_float), ("i", ctypes.c_float)]
+
+
+class OrcTop2(ctypes.Structure):
+    _fields_ = [("val1", ctypes.c_float), ("idx1", ctypes.c_int), ("val2", ctypes.c_float), ("idx2", ctypes.c_int)]
+
+
+class OrcAcq(ctypes.Structure):
+    _fields_ = [("peak", ctypes.c_float), ("second", ctypes.c_float), ("code_phase", ctypes.c_int),
+                ("second_phase", ctypes.c_int), ("doppler_bin", ctypes.c_int), ("prn", ctypes.c_int),
+                ("snr_db", ctypes.c_float), ("code_phase_interp", ctypes.c_float)]
+
+
+_oracle = None
+_ref = None
+
+
+def oracle():
+    """The repo's CPU restatement (oracle/liboracle.so); built on demand with gcc."""
+    global _oracle
+    if _oracle is None:
+        so = os.path.join(ORACLE_DIR, "liboracle.so")
+        srcs = [os.path.join(ORACLE_DIR, f) for f in ("armfft_oracle.c", "gnss_oracle.c", "armfft_oracle.h")]
+        if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+            subprocess.run(["make", "-C", ORACLE_DIR, "liboracle.so"], check=True, capture_output=True)
+        L = ctypes.CDLL(so)
+        L.orc_compute_snr_cplx.restype = ctypes.c_double
+        L.orc_interpolate_code_phase.restype = ctypes.c_double
+        L.orc_interpolate_code_phase.argtypes = [ctypes.c_uint32, ctypes.c_double, ctypes.c_double, ctypes.c_double]
+        L.orc_mix_prn.argtypes = [c_i32, ctypes.c_double, ctypes.c_double, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        L.orc_synth_gps_prn.argtypes = [ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+        L.orc_compute_snr_cplx.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_int]
+        L.orc_acquire_cell_reference.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int,
+                                                 ctypes.POINTER(OrcTop2), ctypes.c_void_p]
+        _oracle = L
+    return _oracle
+
+
+def ref():
+    """The reference's own code compiled here (oracle/_ref/libcmsis_ref.so), or None when it was
+    not built (the GPU box only has it if the tree was built where /root/reference exists)."""
+    global _ref
+    if _ref is None:
+        so = os.path.join(ORACLE_DIR, "_ref", "libcmsis_ref.so")
+        if not os.path.exists(so):
+            if os.path.isdir("/root/reference"):
+                subprocess.run(["make", "-C", ORACLE_DIR, "ref"], check=True, capture_output=True)
+            else:
+                return None
+        _ref = ctypes.CDLL(so)
+    return _ref
+
+
+_golden = {}
+
+
+def golden(kind):
+    if kind not in _golden:
+        _golden[kind] = np.load(os.path.join(GOLDEN_DIR, "transform_%s.npz" % kind), allow_pickle=False)
+    return _golden[kind]
+
+
+CFFT_SIZES = [16, 32, 64, 128, 256, 512, 1024, 2048, 4096]
+# pattern ids of Testing/Patterns/DSP/Transform (Noisy 1..9, Step 10..18 for sizes 16..4096)
+NOISY_ID = {16: 1, 32: 2, 64: 3, 128: 4, 256: 5, 512: 6, 1024: 7, 2048: 8, 4096: 9}
+STEP_ID = {16: 10, 32: 11, 64: 12, 128: 13, 256: 14, 512: 15, 1024: 16, 2048: 17, 4096: 18}
+
+
+def golden_case(kind, domain, sig, n):
+    """(input, fft, ifft_input) arrays of one reference pattern set."""
+    g = golden(kind)
+    tid = NOISY_ID[n] if sig == "noisy" else STEP_ID[n]
+    key = lambda what: "%s_%s_%s_%d_%d" % (domain, what, sig, n, tid)
+    return g[key("in")], g[key("fft")], g[key("ifftin")]
+
+
+# ---- the reference's assertion semantics (Testing/FrameworkSource/Error.cpp:397-406, :515-544) ----
+def snr_db(ref_v, test_v):
+    ref_v = np.asarray(ref_v, dtype=np.float64)
+    test_v = np.asarray(test_v, dtype=np.float64)
+    e = np.sum(ref_v ** 2)
+    d = np.sum((ref_v - test_v) ** 2)
+    if d == 0:
+        return 1e5
+    return 10.0 * np.log10(e / d)
+
+
+def assert_close_error(test_v, ref_v, abs_err, rel_err, known_miss=(), miss_abs=0.0):
+    """|test - ref| <= abs + rel*|ref| per sample; indices in known_miss get miss_abs instead."""
+    test_v = np.asarray(test_v, dtype=np.float64)
+    ref_v = np.asarray(ref_v, dtype=np.float64)
+    err = np.abs(test_v - ref_v)
+    bad = err > abs_err + rel_err * np.abs(ref_v)
+    for i in known_miss:
+        if bad[i] and err[i] <= miss_abs:
+            bad[i] = False
+    assert not bad.any(), "close-error failed at %d of %d samples (first %d)" % (bad.sum(), bad.size, np.argmax(bad))
+
+
+# The reference's OWN generic-C arm_rfft_fast_f32 (oracle/_ref, regenerated tables) misses its
+# 5e-5 absolute bound at exactly one bin of one pattern: RealFFTSamples_Step_4096, imag of the last
+# bin (value 6.9e-4 next to 1e3-sized neighbours, error 8.0e-5).  Kept as a documented exception
+# so that every other sample stays under the reference's thresholds.
+RFFT_KNOWN_MISS = {(4096, "step"): ((4095,), 1.5e-4)}
+
+
+def rel_l2(test_v, ref_v):
+    test_v = np.asarray(test_v, dtype=np.float64)
+    ref_v = np.asarray(ref_v, dtype=np.float64)
+    return np.linalg.norm(test_v - ref_v) / max(np.linalg.norm(ref_v), 1e-300)
+
+
+def rng(seed):
+    return np.random.Generator(np.random.Philox(seed))
