@@ -65,7 +65,7 @@ def _load():
         raise ImportError(
             "%s is missing: build it with `python -m fft_amd.build` (hipcc, gfx950). "
             "fft_amd has no CPU fallback." % path)
-    L = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+    L = ctypes.CDLL(path)  # RTLD_LOCAL: the arm_* names must not leak into other libraries
     u8, u16, u32 = c_uint8, c_uint16, c_uint32
     for T, inst, scalar in (("f32", arm_cfft_instance_f32, c_float), ("q15", arm_cfft_instance_q15, c_int16),
                             ("q31", arm_cfft_instance_q31, c_int32)):
