@@ -65,6 +65,14 @@ def _load():
         raise ImportError(
             "%s is missing: build it with `python -m fft_amd.build` (hipcc, gfx950). "
             "fft_amd has no CPU fallback." % path)
+    # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64.so.7.  If torch is going to
+    # be used in this process (tests, bench: device memory and streams) it must be loaded FIRST so
+    # that this library's DT_NEEDED libamdhip64.so.7 resolves to the copy already mapped; loading
+    # the system ROCm runtime first and torch's second leaves two runtimes fighting over the GPU.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     L = ctypes.CDLL(path)  # RTLD_LOCAL: the arm_* names must not leak into other libraries
     u8, u16, u32 = c_uint8, c_uint16, c_uint32
     for T, inst, scalar in (("f32", arm_cfft_instance_f32, c_float), ("q15", arm_cfft_instance_q15, c_int16),

@@ -29,32 +29,46 @@ __device__ __forceinline__ int scrambled_pos(int k)
   return (d0 << (3 * N8)) | low;
 }
 
+// Per-size tuning (measured on MI355X, tools/fft4096_lab.hip, profiles/r01_lab_*.txt):
+//   HMASK  passes whose twiddles a persistent workgroup keeps in registers (bit p = pass p)
+//   MINW   __launch_bounds__ waves per SIMD (register budget 512/MINW)
+//   WGPCU  persistent workgroups per CU (0 = one workgroup per group of transforms, no loop)
+// 4096 points: the per-transform twiddle loads (30 per thread, L1/L2 hits) cost 20 % of the
+// run time of the non-persistent kernel; with both twiddled passes in registers and 2
+// workgroups per CU the kernel streams at the same rate as a plain in-place copy.
+template <int LOGN> struct Tune { static constexpr unsigned HMASK = 0; static constexpr int MINW = 4, WGPCU = 0; };
+template <> struct Tune<12> { static constexpr unsigned HMASK = 6; static constexpr int MINW = 2, WGPCU = 2; };
+
 template <int LOGN, bool INV>
-__global__ __launch_bounds__(Plan<LOGN>::T, 4) void cfft_f32_kernel(float2 *__restrict__ data, const float2 *__restrict__ tw,
-                                                                 uint32_t batch, uint32_t ngroups, int scramble)
+__global__ __launch_bounds__(Plan<LOGN>::T, Tune<LOGN>::MINW) void cfft_f32_kernel(float2 *__restrict__ data, const float2 *__restrict__ tw,
+                                                                                 uint32_t batch, uint32_t ngroups, int scramble)
 {
   using PL = Plan<LOGN>;
   extern __shared__ __attribute__((aligned(16))) float2 lds[];
-  const int tid = threadIdx.x;
   const float inv_n = 1.0f / (float)PL::N;
-  {
-    const uint32_t g = blockIdx.x + blockIdx.y * gridDim.x;
-    if (g >= ngroups) return;
+  TwRegs<LOGN, Tune<LOGN>::HMASK> twr;
+  twr.tw = tw;
+  twr.preload(threadIdx.x);
+  const uint32_t g0 = blockIdx.x + blockIdx.y * gridDim.x, gstep = gridDim.x * gridDim.y;
+  for (uint32_t g = g0; g < ngroups; g += gstep) {
+    int tid = threadIdx.x;
+    if (Tune<LOGN>::WGPCU) asm volatile("" : "+v"(tid));  // keep per-thread address math inside the loop
     const uint32_t t0 = g * PL::TPB;
+    float2 *__restrict__ p = data + (size_t)t0 * PL::N;     // uniform base, 32-bit per-lane offsets
     auto ld = [&](int t, int e) -> float2 {
-      const uint32_t tr = t0 + t;
       float2 v = make_float2(0.f, 0.f);
-      if (tr < batch) v = data[(size_t)tr * PL::N + e];
+      if (t0 + t < batch) v = p[t * PL::N + e];
       if (INV) v.y = -v.y;
       return v;
     };
     auto st = [&](int t, int e, float2 v) {
-      const uint32_t tr = t0 + t;
       if (INV) v = make_float2(v.x * inv_n, -v.y * inv_n);
       if (scramble) e = scrambled_pos<LOGN>(e);
-      if (tr < batch) data[(size_t)tr * PL::N + e] = v;
+      if (t0 + t < batch) p[t * PL::N + e] = v;
     };
-    fft_block<LOGN, false, false>(lds, tw, tid, ld, st);
+    fft_block_tw<LOGN, false, false>(lds, twr, tid, ld, st);
+    if (Tune<LOGN>::WGPCU == 0) break;
+    __syncthreads();  // the next transform's first LDS write must not overtake this one's last read
   }
 }
 
@@ -160,6 +174,18 @@ hipError_t launch_gen_twiddle_rfft(float2 *tw, uint32_t n_real, hipStream_t stre
 }
 
 // ---- launchers ----
+static int cu_count(int dev)
+{
+  static int cus[16] = {0};
+  if (dev < 0 || dev >= 16) return 256;
+  if (!cus[dev]) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cus[dev] = n;
+  }
+  return cus[dev];
+}
+
 static dim3 grid_for(uint32_t ngroups)
 {
   // one workgroup per group of TPB transforms; fold very large batches into grid.y
@@ -173,7 +199,7 @@ static hipError_t launch_cfft_one(float2 *data, const float2 *tw, uint32_t batch
   using PL = Plan<LOGN>;
   static bool attr_done[16] = {false};
   int dev = 0;
-  hipGetDevice(&dev);
+  (void)hipGetDevice(&dev);
   auto kern = cfft_f32_kernel<LOGN, INV>;
   if (PL::LDS_BYTES > 48 * 1024 && dev < 16 && !attr_done[dev]) {
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PL::LDS_BYTES);
@@ -181,7 +207,12 @@ static hipError_t launch_cfft_one(float2 *data, const float2 *tw, uint32_t batch
     attr_done[dev] = true;
   }
   const uint32_t ngroups = (batch + PL::TPB - 1) / PL::TPB;
-  kern<<<grid_for(ngroups), PL::T, PL::LDS_BYTES, stream>>>(data, tw, batch, ngroups, scramble ? 1 : 0);
+  dim3 grid = grid_for(ngroups);
+  if (Tune<LOGN>::WGPCU) {
+    const uint32_t resident = (uint32_t)Tune<LOGN>::WGPCU * (uint32_t)cu_count(dev);
+    if (ngroups > resident) grid = dim3(resident, 1, 1);
+  }
+  kern<<<grid, PL::T, PL::LDS_BYTES, stream>>>(data, tw, batch, ngroups, scramble ? 1 : 0);
   return hipGetLastError();
 }
 
@@ -205,7 +236,7 @@ static hipError_t launch_rfft_one(const float2 *in, float2 *out, const float2 *t
   using PL = Plan<LOGM>;
   static bool attr_done[16] = {false};
   int dev = 0;
-  hipGetDevice(&dev);
+  (void)hipGetDevice(&dev);
   auto kern = rfft_f32_kernel<LOGM, INV>;
   if (PL::LDS_BYTES > 48 * 1024 && dev < 16 && !attr_done[dev]) {
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PL::LDS_BYTES);

@@ -14,6 +14,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace armfft {
 
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
@@ -127,10 +129,65 @@ struct Plan {
 
 __device__ __forceinline__ int lds_pad(int e) { return e + ((e >> 4) << 1); }
 
+// Load tag: the caller has already placed the first pass's inputs in v[] (same order the gather
+// would have produced: butterfly q = 0..16/R-1 of thread tid is w = tid + q*T, leg r at v[q*R + r]
+// holds point (w mod N/R) + r*N/R of sequence w / (N/R)).  Used by software-pipelined kernels
+// that prefetch the next transform while the current one is in flight.
+struct Preloaded {
+  __device__ __forceinline__ float2 operator()(int, int) const { return make_float2(0.f, 0.f); }
+};
+
+// ---- twiddle sources ----
+// The pass code asks for twiddle `slot` (= q*(R-1) + r-1) of pass P, whose table index is idx.
+// TwTable reads the device-generated table (L1/L2-resident, never HBM in steady state).
+struct TwTable {
+  const float2 *__restrict__ tw;
+  template <int P>
+  __device__ __forceinline__ float2 get(int /*slot*/, int idx) const { return tw[idx]; }
+};
+
+// TwRegs keeps the twiddles of the passes in HMASK (bit p = pass p) in registers: they depend only
+// on the thread index, so a persistent workgroup loads them once and reuses them for every
+// transform it processes.  The other passes read the table.
+template <int LOGN, unsigned HMASK>
+struct TwRegs {
+  const float2 *__restrict__ tw;
+  float2 w[Plan<LOGN>::NPASS][15];
+
+  template <int P>
+  __device__ __forceinline__ void preload_pass(int tid)
+  {
+    using PL = Plan<LOGN>;
+    if constexpr (P < PL::NPASS) {
+      if constexpr (P > 0 && ((HMASK >> P) & 1u)) {
+        constexpr int LR = PL::lr(P), R = 1 << LR, NB = 16 / R, LNS = PL::lns(P), NS = 1 << LNS, LNR = LOGN - LR;
+#pragma unroll
+        for (int q = 0; q < NB; q++) {
+          const int j = (tid + q * PL::T) & ((1 << LNR) - 1);
+          const int stepk = (j & (NS - 1)) << (LOGN - LNS - LR);
+#pragma unroll
+          for (int r = 1; r < R; r++) w[P][q * (R - 1) + r - 1] = tw[r * stepk];
+        }
+      }
+      preload_pass<P + 1>(tid);
+    }
+  }
+  __device__ __forceinline__ void preload(int tid) { preload_pass<0>(tid); }
+
+  template <int P>
+  __device__ __forceinline__ float2 get(int slot, int idx) const
+  {
+    if constexpr ((HMASK >> P) & 1u)
+      return w[P][slot];
+    else
+      return tw[idx];
+  }
+};
+
 // One pass.  P = pass index.  v holds the thread's 16 points: butterfly q (0..16/R-1), leg r at
 // v[q*R + r].
-template <int LOGN, int P, bool LDS_IN, bool LDS_OUT, class Load, class Store>
-__device__ __forceinline__ void fft_pass(float2 *v, float2 *lds, const float2 *__restrict__ tw, int tid, Load &ld, Store &st)
+template <int LOGN, int P, bool LDS_IN, bool LDS_OUT, class TW, class Load, class Store>
+__device__ __forceinline__ void fft_pass(float2 *v, float2 *lds, const TW &tw, int tid, Load &ld, Store &st)
 {
   using PL = Plan<LOGN>;
   constexpr int N = PL::N, T = PL::T;
@@ -147,10 +204,11 @@ __device__ __forceinline__ void fft_pass(float2 *v, float2 *lds, const float2 *_
 #pragma unroll
     for (int r = 0; r < R; r++) {
       const int e = j + (r << LNR);
-      if (FIRST)
-        v[q * R + r] = ld(t, e);
-      else
+      if constexpr (FIRST) {
+        if constexpr (!std::is_same<Load, Preloaded>::value) v[q * R + r] = ld(t, e);
+      } else {
         v[q * R + r] = lds[lds_pad(t * N + e)];
+      }
     }
   }
   // ---- twiddle + butterfly ----
@@ -163,7 +221,7 @@ __device__ __forceinline__ void fft_pass(float2 *v, float2 *lds, const float2 *_
       // W_{NS*R}^{r k} = tw[r * k * N/(NS*R)]
       const int stepk = k << (LOGN - LNS - LR);
 #pragma unroll
-      for (int r = 1; r < R; r++) v[q * R + r] = cmul(v[q * R + r], tw[r * stepk]);
+      for (int r = 1; r < R; r++) v[q * R + r] = cmul(v[q * R + r], tw.template get<P>(q * (R - 1) + r - 1, r * stepk));
     }
     butterfly<R>(v + q * R);
   }
@@ -194,12 +252,12 @@ __device__ __forceinline__ void fft_pass(float2 *v, float2 *lds, const float2 *_
   if (!LAST) __syncthreads();
 }
 
-template <int LOGN, int P, bool LDS_IN, bool LDS_OUT, class Load, class Store>
+template <int LOGN, int P, bool LDS_IN, bool LDS_OUT, class TW, class Load, class Store>
 struct PassLoop {
-  static __device__ __forceinline__ void run(float2 *v, float2 *lds, const float2 *__restrict__ tw, int tid, Load &ld, Store &st)
+  static __device__ __forceinline__ void run(float2 *v, float2 *lds, const TW &tw, int tid, Load &ld, Store &st)
   {
     fft_pass<LOGN, P, LDS_IN, LDS_OUT>(v, lds, tw, tid, ld, st);
-    if constexpr (P + 1 < Plan<LOGN>::NPASS) PassLoop<LOGN, P + 1, LDS_IN, LDS_OUT, Load, Store>::run(v, lds, tw, tid, ld, st);
+    if constexpr (P + 1 < Plan<LOGN>::NPASS) PassLoop<LOGN, P + 1, LDS_IN, LDS_OUT, TW, Load, Store>::run(v, lds, tw, tid, ld, st);
   }
 };
 
@@ -209,11 +267,26 @@ struct PassLoop {
 // st() calls of this thread have been issued (no trailing barrier).  LDS_IN / LDS_OUT: set when
 // ld() reads / st() writes the workgroup's LDS (anywhere), so that the core separates them from
 // its own LDS traffic with a barrier.
+template <int LOGN, bool LDS_IN, bool LDS_OUT, class TW, class Load, class Store>
+__device__ __forceinline__ void fft_block_tw(float2 *lds, const TW &tw, int tid, Load ld, Store st)
+{
+  float2 v[16];
+  PassLoop<LOGN, 0, LDS_IN, LDS_OUT, TW, Load, Store>::run(v, lds, tw, tid, ld, st);
+}
+
 template <int LOGN, bool LDS_IN, bool LDS_OUT, class Load, class Store>
 __device__ __forceinline__ void fft_block(float2 *lds, const float2 *__restrict__ tw, int tid, Load ld, Store st)
 {
-  float2 v[16];
-  PassLoop<LOGN, 0, LDS_IN, LDS_OUT, Load, Store>::run(v, lds, tw, tid, ld, st);
+  TwTable t{tw};
+  fft_block_tw<LOGN, LDS_IN, LDS_OUT>(lds, t, tid, ld, st);
+}
+
+// Same with the first pass's inputs already in v[16] (see Preloaded).
+template <int LOGN, bool LDS_OUT, class TW, class Store>
+__device__ __forceinline__ void fft_block_preloaded(float2 *v, float2 *lds, const TW &tw, int tid, Store st)
+{
+  Preloaded ld;
+  PassLoop<LOGN, 0, false, LDS_OUT, TW, Preloaded, Store>::run(v, lds, tw, tid, ld, st);
 }
 
 }  // namespace armfft
