@@ -36,6 +36,8 @@ WORKLOADS = {
     "cfft_q15_4096x65536": dict(kind="q15", n=4096, batch=65536, dtype="q15"),
     "cfft_q31_4096x65536": dict(kind="q31", n=4096, batch=65536, dtype="q31"),
     "rfft_f32_16384x16384": dict(kind="rfft", n=16384, batch=16384, dtype="f32"),
+    "cfft_f32_4194304x8": dict(kind="large", n=1 << 22, batch=8, dtype="f32"),   # BASELINE config 4, four-step
+    "cfft_f32_4194304x64": dict(kind="large", n=1 << 22, batch=64, dtype="f32"),
 }
 
 
@@ -58,6 +60,8 @@ def cpu_baseline(kind, n, seconds):
     import numpy as np
     ref_so = os.path.join(ROOT, "oracle", "_ref", "libcmsis_ref.so")
     orc_so = os.path.join(ROOT, "oracle", "liboracle.so")
+    if kind == "large":
+        return cpu_baseline_large(n, seconds)
     use_ref = os.path.exists(ref_so) and kind in ("f32", "q15", "q31") and n <= 4096
     use_ref = use_ref or (os.path.exists(ref_so) and kind == "rfft" and n <= 4096)
     if use_ref:
@@ -134,6 +138,36 @@ def cpu_baseline(kind, n, seconds):
     }
 
 
+def cpu_baseline_large(n, seconds):
+    """No reference function runs N > 16384; the fork's own largest path (radix-2 f32, 16384 points,
+    arm_cfft_radix2_f32.c) is what a CMSIS caller would have to build on, so that is what is timed."""
+    import numpy as np
+    ref_so = os.path.join(ROOT, "oracle", "_ref", "libcmsis_ref.so")
+    orc_so = os.path.join(ROOT, "oracle", "liboracle.so")
+    cn = 16384
+    if os.path.exists(ref_so):
+        L, which = ctypes.CDLL(ref_so), "reference"
+        call = lambda a: L.ref_cfft_radix2_f32(a.ctypes.data_as(ctypes.c_void_p), cn, 1, 0, 1)
+    elif os.path.exists(orc_so):
+        L, which = ctypes.CDLL(orc_so), "port"
+        call = lambda a: L.orc_cfft_radix2_f32(a.ctypes.data_as(ctypes.c_void_p), cn, 0, 1)
+    else:
+        return None
+    proto = np.random.default_rng(4).uniform(-1, 1, 2 * cn).astype(np.float32)
+    work = proto.copy()
+    call(work)
+    busy, done, deadline = 0.0, 0, time.perf_counter() + seconds
+    while time.perf_counter() < deadline:
+        np.copyto(work, proto)
+        t0 = time.perf_counter()
+        call(work)
+        busy += time.perf_counter() - t0
+        done += 1
+    return {"value": round(done / busy * 5.0 * cn * 14 / 1e9, 3), "unit": "GFLOP/s", "cores": 1, "kind": which,
+            "sample": "arm_cfft_radix2_f32 forward, 16384 points (the fork's largest transform; nothing in the reference runs %d), "
+                      "%d transforms in %.0f s on one core" % (n, done, seconds)}
+
+
 def main():
     args = parse()
     import numpy as np
@@ -173,6 +207,19 @@ def main():
         rescale = lambda: data.mul_(2.0 ** (-6 * chunk))
         bytes_per_xform, flops_per_xform = 16 * n, 5.0 * n * np.log2(n)
         kernel_name = "cfft_f32_kernel<12, false>"
+    elif kind == "large":
+        S = fft_amd.arm_cfft_instance_u32_f32()
+        assert lib.arm_cfft_init_u32_f32(ctypes.byref(S), n) == 0
+        chunk = 4
+        amp = 2.0 ** -48
+        data = ((torch.rand((batch, 2 * n), device="cuda", generator=gen) * 2 - 1) * amp).contiguous()
+        work = torch.empty_like(data)
+        step = lambda: lib.arm_cfft_u32_f32_dev(ctypes.byref(S), ctypes.c_void_p(data.data_ptr()), ctypes.c_void_p(work.data_ptr()),
+                                                batch, 0, stream)
+        rescale = lambda: data.mul_(2.0 ** (-11 * chunk))
+        # algorithmic bytes per SURVEY 8(d): 16*N per transform; the four-step moves every point twice
+        bytes_per_xform, flops_per_xform = 16 * n, 5.0 * n * np.log2(n)
+        kernel_name = "fourstep_pass_kernel<11, 1|2, false> (two launches per step)"
     elif kind in ("q15", "q31"):
         I = fft_amd.arm_cfft_instance_q15 if kind == "q15" else fft_amd.arm_cfft_instance_q31
         S = I()
@@ -234,8 +281,8 @@ def main():
         elapsed, kernel_ms = float(t[0]), float(t[1])
 
     finite = True
-    if kind in ("f32", "rfft"):
-        finite = bool(torch.isfinite(data if kind == "f32" else out).all())
+    if kind in ("f32", "rfft", "large"):
+        finite = bool(torch.isfinite(out if kind == "rfft" else data).all())
 
     if rank == 0:
         total_xforms = batch * K * world

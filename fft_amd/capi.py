@@ -6,7 +6,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int16, c_int3
 
 __all__ = [
     "lib", "lib_path", "ARM_MATH_SUCCESS", "ARM_MATH_ARGUMENT_ERROR",
-    "arm_cfft_instance_f32", "arm_cfft_instance_q15", "arm_cfft_instance_q31", "arm_rfft_fast_instance_f32",
+    "arm_cfft_instance_u32_f32", "arm_cfft_instance_f32", "arm_cfft_instance_q15", "arm_cfft_instance_q31", "arm_rfft_fast_instance_f32",
     "last_error", "EXPORTED_SYMBOLS",
 ]
 
@@ -35,6 +35,10 @@ class arm_cfft_instance_q31(Structure):
                 ("bitRevLength", c_uint16)]
 
 
+class arm_cfft_instance_u32_f32(Structure):
+    _fields_ = [("fftLen", c_uint32)]
+
+
 class arm_rfft_fast_instance_f32(Structure):
     _fields_ = [("Sint", arm_cfft_instance_f32), ("fftLenRFFT", c_uint16), ("pTwiddleRFFT", POINTER(c_float))]
 
@@ -54,6 +58,7 @@ EXPORTED_SYMBOLS = (
     + ["arm_cfft_init_%d_q31" % n for n in _Q31_SIZES]
     + ["arm_rfft_fast_init_f32", "arm_rfft_fast_f32", "arm_rfft_fast_batch_f32", "arm_rfft_fast_f32_dev"]
     + ["arm_rfft_fast_init_%d_f32" % n for n in _RFFT_SIZES]
+    + ["arm_cfft_init_u32_f32", "arm_cfft_u32_f32_dev", "arm_cfft_u32_batch_f32"]
     + ["arm_fft_mi355_set_device", "arm_fft_mi355_warm", "arm_fft_mi355_last_error",
        "arm_fft_mi355_set_twiddle_rounding", "arm_fft_mi355_version"]
 )
@@ -99,6 +104,10 @@ def _load():
     L.arm_rfft_fast_f32.argtypes, L.arm_rfft_fast_f32.restype = [POINTER(R), c_void_p, c_void_p, u8], None
     L.arm_rfft_fast_batch_f32.argtypes, L.arm_rfft_fast_batch_f32.restype = [POINTER(R), c_void_p, c_void_p, u32, u8], c_int
     L.arm_rfft_fast_f32_dev.argtypes, L.arm_rfft_fast_f32_dev.restype = [POINTER(R), c_void_p, c_void_p, u32, u8, c_void_p], c_int
+    U = arm_cfft_instance_u32_f32
+    L.arm_cfft_init_u32_f32.argtypes, L.arm_cfft_init_u32_f32.restype = [POINTER(U), u32], c_int
+    L.arm_cfft_u32_f32_dev.argtypes, L.arm_cfft_u32_f32_dev.restype = [POINTER(U), c_void_p, c_void_p, u32, u8, c_void_p], c_int
+    L.arm_cfft_u32_batch_f32.argtypes, L.arm_cfft_u32_batch_f32.restype = [POINTER(U), c_void_p, u32, u8], c_int
     L.arm_fft_mi355_set_device.argtypes, L.arm_fft_mi355_set_device.restype = [c_int], c_int
     L.arm_fft_mi355_warm.argtypes, L.arm_fft_mi355_warm.restype = [c_int, u32], c_int
     L.arm_fft_mi355_last_error.argtypes, L.arm_fft_mi355_last_error.restype = [], c_char_p

@@ -237,6 +237,7 @@ struct DevPlans {
   float2 *tw_rfft[kMaxLog + 2] = {};
   int16_t *tw_q15[kMaxLog + 2] = {};
   int32_t *tw_q31[kMaxLog + 2] = {};
+  float2 *tw_lo[kMaxLargeLog + 1] = {};
   void *stage = nullptr;  // grow-only staging buffers for the host-pointer entry points
   size_t stage_bytes = 0;
   void *stage2 = nullptr;
@@ -287,6 +288,22 @@ static const float2 *dev_tw_rfft(int logn_real)
     uint32_t N = 1u << logn_real;
     if (!hip_ok(hipMalloc((void **)&p, sizeof(float2) * (N / 2)), "hipMalloc(rfft twiddle)")) { p = nullptr; return nullptr; }
     if (!hip_ok(launch_gen_twiddle_rfft(p, N, nullptr), "rfft twiddle generation") || !hip_ok(hipStreamSynchronize(nullptr), "sync")) {
+      (void)hipFree(p);
+      p = nullptr;
+    }
+  }
+  return p;
+}
+
+static const float2 *dev_tw_lo(int logn)
+{
+  int dev;
+  if (!current_device(&dev)) return nullptr;
+  std::lock_guard<std::mutex> lk(g_dev_mu);
+  float2 *&p = g_dev[dev].tw_lo[logn];
+  if (!p) {
+    if (!hip_ok(hipMalloc((void **)&p, sizeof(float2) * 2048), "hipMalloc(lo twiddle)")) { p = nullptr; return nullptr; }
+    if (!hip_ok(launch_gen_twiddle_lo(p, logn, nullptr), "lo twiddle generation") || !hip_ok(hipStreamSynchronize(nullptr), "sync")) {
       (void)hipFree(p);
       p = nullptr;
     }
@@ -470,6 +487,56 @@ void arm_cfft_f32(const arm_cfft_instance_f32 *S, float32_t *p1, uint8_t ifftFla
     fprintf(stderr, "libarmfft_mi355: arm_cfft_f32 cannot run (%s)\n", t_err);
     abort();  // a void entry point has no other way to refuse to return wrong data
   }
+}
+
+// ---------------- large f32 complex (four-step) ----------------
+arm_status arm_cfft_init_u32_f32(arm_cfft_instance_u32_f32 *S, uint32_t fftLen)
+{
+  if (!S) return ARM_MATH_ARGUMENT_ERROR;
+  if (!is_pow2(fftLen)) return ARM_MATH_ARGUMENT_ERROR;
+  int l = ilog2u(fftLen);
+  if (l < kMinLog || l > kMaxLargeLog) return ARM_MATH_ARGUMENT_ERROR;
+  S->fftLen = fftLen;
+  return ARM_MATH_SUCCESS;
+}
+
+arm_status arm_cfft_u32_f32_dev(const arm_cfft_instance_u32_f32 *S, float32_t *p, float32_t *work, uint32_t batch, uint8_t ifft,
+                                void *stream)
+{
+  if (!S || !p) { set_error("arm_cfft_u32_f32_dev: null argument"); return ARM_MATH_ARGUMENT_ERROR; }
+  if (!is_pow2(S->fftLen)) { set_error("arm_cfft_u32_f32_dev: unsupported fftLen %u", S->fftLen); return ARM_MATH_ARGUMENT_ERROR; }
+  int l = ilog2u(S->fftLen);
+  if (l >= kMinLog && l <= kMaxLog) {
+    const float2 *tw = dev_tw_f32(l);
+    if (!tw) return ARM_MATH_ARGUMENT_ERROR;
+    return hip_ok(launch_cfft_f32(l, reinterpret_cast<float2 *>(p), tw, batch, ifft != 0, false, (hipStream_t)stream), "cfft_f32 launch")
+               ? ARM_MATH_SUCCESS : ARM_MATH_ARGUMENT_ERROR;
+  }
+  if (l < kMinLargeLog || l > kMaxLargeLog) { set_error("arm_cfft_u32_f32_dev: unsupported fftLen %u", S->fftLen); return ARM_MATH_ARGUMENT_ERROR; }
+  if (!work || work == p) { set_error("arm_cfft_u32_f32_dev: a separate workspace of batch*fftLen*8 bytes is required"); return ARM_MATH_ARGUMENT_ERROR; }
+  const int l2 = l / 2, l1 = l - l2;
+  const float2 *tw1 = dev_tw_f32(l1), *tw2 = dev_tw_f32(l2), *lo = dev_tw_lo(l), *hi = dev_tw_f32(l - 11);
+  if (!tw1 || !tw2 || !lo || !hi) return ARM_MATH_ARGUMENT_ERROR;
+  hipError_t e = launch_cfft_large_f32(l, reinterpret_cast<float2 *>(p), reinterpret_cast<float2 *>(work), tw1, tw2, lo, hi, batch,
+                                       ifft != 0, (hipStream_t)stream);
+  return hip_ok(e, "cfft_large_f32 launch") ? ARM_MATH_SUCCESS : ARM_MATH_ARGUMENT_ERROR;
+}
+
+arm_status arm_cfft_u32_batch_f32(const arm_cfft_instance_u32_f32 *S, float32_t *p, uint32_t batch, uint8_t ifft)
+{
+  if (!S || !p) { set_error("arm_cfft_u32_batch_f32: null argument"); return ARM_MATH_ARGUMENT_ERROR; }
+  if (batch == 0) return ARM_MATH_SUCCESS;
+  int dev;
+  if (!current_device(&dev)) return ARM_MATH_ARGUMENT_ERROR;
+  std::lock_guard<std::mutex> lk(g_stage_mu);
+  size_t bytes = (size_t)S->fftLen * 2 * sizeof(float) * batch;
+  float *d = (float *)stage_buffer(dev, bytes, 0), *w = (float *)stage_buffer(dev, bytes, 1);
+  if (!d || !w) return ARM_MATH_ARGUMENT_ERROR;
+  if (!hip_ok(hipMemcpy(d, p, bytes, hipMemcpyHostToDevice), "hipMemcpy(H2D)")) return ARM_MATH_ARGUMENT_ERROR;
+  arm_status s = arm_cfft_u32_f32_dev(S, d, w, batch, ifft, nullptr);
+  if (s != ARM_MATH_SUCCESS) return s;
+  if (!hip_ok(hipMemcpy(p, d, bytes, hipMemcpyDeviceToHost), "hipMemcpy(D2H)")) return ARM_MATH_ARGUMENT_ERROR;
+  return ARM_MATH_SUCCESS;
 }
 
 // ---------------- q15 complex ----------------

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(Plan<LOGN>::T, Tune<LOGN>::MINW) void cfft_f32_kern
   using PL = Plan<LOGN>;
   extern __shared__ __attribute__((aligned(16))) float2 lds[];
   const float inv_n = 1.0f / (float)PL::N;
-  TwRegs<LOGN, Tune<LOGN>::HMASK> twr;
+  TwRegs<PL, Tune<LOGN>::HMASK> twr;
   twr.tw = tw;
   twr.preload(threadIdx.x);
   const uint32_t g0 = blockIdx.x + blockIdx.y * gridDim.x, gstep = gridDim.x * gridDim.y;
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(Plan<LOGN>::T, Tune<LOGN>::MINW) void cfft_f32_kern
       if (scramble) e = scrambled_pos<LOGN>(e);
       if (t0 + t < batch) p[t * PL::N + e] = v;
     };
-    fft_block_tw<LOGN, false, false>(lds, twr, tid, ld, st);
+    fft_block_tw<PL, false, false>(lds, twr, tid, ld, st);
     if (Tune<LOGN>::WGPCU == 0) break;
     __syncthreads();  // the next transform's first LDS write must not overtake this one's last read
   }
@@ -94,19 +94,19 @@ __global__ __launch_bounds__(Plan<LOGM>::T, 4) void rfft_f32_kernel(const float2
         const uint32_t tr = t0 + t;
         return tr < batch ? in[(size_t)tr * M + e] : make_float2(0.f, 0.f);
       };
-      auto st = [&](int t, int e, float2 v) { lds[lds_pad(t * M + e)] = v; };
-      fft_block<LOGM, false, true>(lds, tw, tid, ld, st);
+      auto st = [&](int t, int e, float2 v) { lds[PL::idx(t, e)] = v; };
+      fft_block<PL, false, true>(lds, tw, tid, ld, st);
       __syncthreads();
       // split: bin k from Z[k] and Z[M-k]
       for (int w = tid; w < PL::TPB * M; w += PL::T) {
         const int t = w >> LOGM, k = w & (M - 1);
         const uint32_t tr = t0 + t;
-        const float2 A = lds[lds_pad(t * M + k)];
+        const float2 A = lds[PL::idx(t, k)];
         float2 o;
         if (k == 0) {
           o = make_float2(A.x + A.y, A.x - A.y);  // 0.5*((2 re) +- (2 im)), exact
         } else {
-          const float2 B = lds[lds_pad(t * M + (M - k))];
+          const float2 B = lds[PL::idx(t, M - k)];
           const float2 c = twr[k];  // (sin, cos)
           const float a = B.x - A.x, b = B.y + A.y;
           o.x = 0.5f * (A.x + B.x + c.x * a + c.y * b);
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(Plan<LOGM>::T, 4) void rfft_f32_kernel(const float2
         const uint32_t tr = t0 + t;
         if (tr < batch) out[(size_t)tr * M + e] = make_float2(v.x * inv_m, -v.y * inv_m);
       };
-      fft_block<LOGM, false, false>(lds, tw, tid, ld, st);
+      fft_block<PL, false, false>(lds, tw, tid, ld, st);
     }
   }
 }

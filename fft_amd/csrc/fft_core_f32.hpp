@@ -110,8 +110,10 @@ __device__ __forceinline__ void butterfly<16>(float2 *v)
 }
 
 // ---- compile-time plan ----
-template <int LOGN>
+// Plan<LOGN, TT>: TT threads per workgroup (0 = default: 256 below 4096 points, N/16 above).
+template <int LOGN_, int TT = 0>
 struct Plan {
+  static constexpr int LOGN = LOGN_;
   static constexpr int N = 1 << LOGN;
   static constexpr int NPASS = (LOGN + 3) / 4;
   static constexpr int BASE = LOGN / NPASS;
@@ -120,14 +122,19 @@ struct Plan {
   static constexpr int lr(int p) { return BASE + (p < EXTRA ? 1 : 0); }
   // log2 of Ns (product of the radices of the passes before p)
   static constexpr int lns(int p) { return p == 0 ? 0 : lns(p - 1) + lr(p - 1); }
-  // threads per workgroup and transforms per workgroup at 16 points per thread
-  static constexpr int T = (N >= 4096) ? N / 16 : 256;
+  // threads per workgroup and sequences per workgroup at 16 points per thread
+  static constexpr int T = TT ? TT : ((N >= 4096) ? N / 16 : 256);
   static constexpr int TPB = (T * 16) / N;
-  static constexpr int LDS_ELEMS = TPB * N + ((TPB * N) >> 4) * 2;  // pad 2 complex per 16
+  static_assert(TPB >= 1 && TPB * N == T * 16, "16 points per thread");
+  // LDS image: each sequence padded by 2 points per 16 (first-pass 16-byte stores and later
+  // 8-byte reads conflict-free or 2-way) and skewed by 2 more points per sequence so that
+  // accesses that walk ACROSS sequences (tile staging, transposes) spread over the banks.
+  static constexpr int SEQ_STRIDE = N + (N >> 4) * 2 + (TPB > 1 ? 2 : 0);
+  static constexpr int LDS_ELEMS = TPB * SEQ_STRIDE;
   static constexpr size_t LDS_BYTES = (size_t)LDS_ELEMS * sizeof(float2);
+  // LDS index of point e of sequence t
+  static __device__ __forceinline__ int idx(int t, int e) { return t * SEQ_STRIDE + e + ((e >> 4) << 1); }
 };
-
-__device__ __forceinline__ int lds_pad(int e) { return e + ((e >> 4) << 1); }
 
 // Load tag: the caller has already placed the first pass's inputs in v[] (same order the gather
 // would have produced: butterfly q = 0..16/R-1 of thread tid is w = tid + q*T, leg r at v[q*R + r]
@@ -149,18 +156,17 @@ struct TwTable {
 // TwRegs keeps the twiddles of the passes in HMASK (bit p = pass p) in registers: they depend only
 // on the thread index, so a persistent workgroup loads them once and reuses them for every
 // transform it processes.  The other passes read the table.
-template <int LOGN, unsigned HMASK>
+template <class PL, unsigned HMASK>
 struct TwRegs {
   const float2 *__restrict__ tw;
-  float2 w[Plan<LOGN>::NPASS][15];
+  float2 w[PL::NPASS][15];
 
   template <int P>
   __device__ __forceinline__ void preload_pass(int tid)
   {
-    using PL = Plan<LOGN>;
     if constexpr (P < PL::NPASS) {
       if constexpr (P > 0 && ((HMASK >> P) & 1u)) {
-        constexpr int LR = PL::lr(P), R = 1 << LR, NB = 16 / R, LNS = PL::lns(P), NS = 1 << LNS, LNR = LOGN - LR;
+        constexpr int LOGN = PL::LOGN, LR = PL::lr(P), R = 1 << LR, NB = 16 / R, LNS = PL::lns(P), NS = 1 << LNS, LNR = LOGN - LR;
 #pragma unroll
         for (int q = 0; q < NB; q++) {
           const int j = (tid + q * PL::T) & ((1 << LNR) - 1);
@@ -186,11 +192,10 @@ struct TwRegs {
 
 // One pass.  P = pass index.  v holds the thread's 16 points: butterfly q (0..16/R-1), leg r at
 // v[q*R + r].
-template <int LOGN, int P, bool LDS_IN, bool LDS_OUT, class TW, class Load, class Store>
+template <class PL, int P, bool LDS_IN, bool LDS_OUT, class TW, class Load, class Store>
 __device__ __forceinline__ void fft_pass(float2 *v, float2 *lds, const TW &tw, int tid, Load &ld, Store &st)
 {
-  using PL = Plan<LOGN>;
-  constexpr int N = PL::N, T = PL::T;
+  constexpr int LOGN = PL::LOGN, T = PL::T;
   constexpr int LR = PL::lr(P), R = 1 << LR, NB = 16 / R;
   constexpr int LNS = PL::lns(P), NS = 1 << LNS;
   constexpr int LNR = LOGN - LR;  // log2(N/R): butterflies per transform
@@ -207,7 +212,7 @@ __device__ __forceinline__ void fft_pass(float2 *v, float2 *lds, const TW &tw, i
       if constexpr (FIRST) {
         if constexpr (!std::is_same<Load, Preloaded>::value) v[q * R + r] = ld(t, e);
       } else {
-        v[q * R + r] = lds[lds_pad(t * N + e)];
+        v[q * R + r] = lds[PL::idx(t, e)];
       }
     }
   }
@@ -241,52 +246,52 @@ __device__ __forceinline__ void fft_pass(float2 *v, float2 *lds, const TW &tw, i
       // NS == 1: R consecutive points per butterfly -> 16-byte LDS stores
 #pragma unroll
       for (int r = 0; r < R; r += 2) {
-        const int e = t * N + j * R + r;
-        *reinterpret_cast<float4 *>(&lds[lds_pad(e)]) = make_float4(v[q * R + r].x, v[q * R + r].y, v[q * R + r + 1].x, v[q * R + r + 1].y);
+        *reinterpret_cast<float4 *>(&lds[PL::idx(t, j * R + r)]) =
+            make_float4(v[q * R + r].x, v[q * R + r].y, v[q * R + r + 1].x, v[q * R + r + 1].y);
       }
     } else {
 #pragma unroll
-      for (int r = 0; r < R; r++) lds[lds_pad(t * N + j0 + (r << LNS))] = v[q * R + r];
+      for (int r = 0; r < R; r++) lds[PL::idx(t, j0 + (r << LNS))] = v[q * R + r];
     }
   }
   if (!LAST) __syncthreads();
 }
 
-template <int LOGN, int P, bool LDS_IN, bool LDS_OUT, class TW, class Load, class Store>
+template <class PL, int P, bool LDS_IN, bool LDS_OUT, class TW, class Load, class Store>
 struct PassLoop {
   static __device__ __forceinline__ void run(float2 *v, float2 *lds, const TW &tw, int tid, Load &ld, Store &st)
   {
-    fft_pass<LOGN, P, LDS_IN, LDS_OUT>(v, lds, tw, tid, ld, st);
-    if constexpr (P + 1 < Plan<LOGN>::NPASS) PassLoop<LOGN, P + 1, LDS_IN, LDS_OUT, TW, Load, Store>::run(v, lds, tw, tid, ld, st);
+    fft_pass<PL, P, LDS_IN, LDS_OUT>(v, lds, tw, tid, ld, st);
+    if constexpr (P + 1 < PL::NPASS) PassLoop<PL, P + 1, LDS_IN, LDS_OUT, TW, Load, Store>::run(v, lds, tw, tid, ld, st);
   }
 };
 
 // Transform the workgroup's TPB sequences.  ld(t, e) returns point e of sequence t (t < TPB),
-// st(t, e, val) receives output bin e of sequence t.  `lds` must hold Plan<LOGN>::LDS_ELEMS float2
+// st(t, e, val) receives output bin e of sequence t.  `lds` must hold PL::LDS_ELEMS float2
 // (16-byte aligned) and must not be in use by other threads when the call starts; on return all
 // st() calls of this thread have been issued (no trailing barrier).  LDS_IN / LDS_OUT: set when
 // ld() reads / st() writes the workgroup's LDS (anywhere), so that the core separates them from
 // its own LDS traffic with a barrier.
-template <int LOGN, bool LDS_IN, bool LDS_OUT, class TW, class Load, class Store>
+template <class PL, bool LDS_IN, bool LDS_OUT, class TW, class Load, class Store>
 __device__ __forceinline__ void fft_block_tw(float2 *lds, const TW &tw, int tid, Load ld, Store st)
 {
   float2 v[16];
-  PassLoop<LOGN, 0, LDS_IN, LDS_OUT, TW, Load, Store>::run(v, lds, tw, tid, ld, st);
+  PassLoop<PL, 0, LDS_IN, LDS_OUT, TW, Load, Store>::run(v, lds, tw, tid, ld, st);
 }
 
-template <int LOGN, bool LDS_IN, bool LDS_OUT, class Load, class Store>
+template <class PL, bool LDS_IN, bool LDS_OUT, class Load, class Store>
 __device__ __forceinline__ void fft_block(float2 *lds, const float2 *__restrict__ tw, int tid, Load ld, Store st)
 {
   TwTable t{tw};
-  fft_block_tw<LOGN, LDS_IN, LDS_OUT>(lds, t, tid, ld, st);
+  fft_block_tw<PL, LDS_IN, LDS_OUT>(lds, t, tid, ld, st);
 }
 
 // Same with the first pass's inputs already in v[16] (see Preloaded).
-template <int LOGN, bool LDS_OUT, class TW, class Store>
+template <class PL, bool LDS_OUT, class TW, class Store>
 __device__ __forceinline__ void fft_block_preloaded(float2 *v, float2 *lds, const TW &tw, int tid, Store st)
 {
   Preloaded ld;
-  PassLoop<LOGN, 0, false, LDS_OUT, TW, Preloaded, Store>::run(v, lds, tw, tid, ld, st);
+  PassLoop<PL, 0, false, LDS_OUT, TW, Preloaded, Store>::run(v, lds, tw, tid, ld, st);
 }
 
 }  // namespace armfft

@@ -170,6 +170,21 @@ arm_status arm_rfft_fast_batch_f32(const arm_rfft_fast_instance_f32 *S, float32_
 arm_status arm_rfft_fast_f32_dev(const arm_rfft_fast_instance_f32 *S, const float32_t *p_dev, float32_t *pOut_dev,
                                  uint32_t batch, uint8_t ifftFlag, void *stream);
 
+/* ---- large complex f32 FFT, 2^15 <= fftLen <= 2^22 (extension; BASELINE config 4) ----
+ * No reference function runs these sizes: arm_cfft_f32 stops at 4096 (arm_cfft_f32.c:1263-1280) and
+ * fftLen is a uint16_t in every reference instance (transform_functions.h:416-430), hence the
+ * widened instance.  Four-step decomposition through HBM; needs a caller-provided device workspace
+ * of the same size as the data (batch * fftLen * 8 bytes).  fftLen <= 16384 is routed to the
+ * single-kernel path and ignores the workspace. */
+typedef struct {
+  uint32_t fftLen;
+} arm_cfft_instance_u32_f32;
+arm_status arm_cfft_init_u32_f32(arm_cfft_instance_u32_f32 *S, uint32_t fftLen);
+arm_status arm_cfft_u32_f32_dev(const arm_cfft_instance_u32_f32 *S, float32_t *p1_dev, float32_t *work_dev, uint32_t batch,
+                                uint8_t ifftFlag, void *stream);
+/* host pointers; allocates its own device staging */
+arm_status arm_cfft_u32_batch_f32(const arm_cfft_instance_u32_f32 *S, float32_t *p1, uint32_t batch, uint8_t ifftFlag);
+
 /* ---- library services (no counterpart in the reference) ---- */
 /* Select the GPU used by the calling thread's host-pointer entry points and build nothing else;
  * optional (device 0 / the current HIP device is used otherwise). */

@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256, MINW) void v0(float2 *__restrict__ data, const
   const uint32_t b = blockIdx.x;
   auto ld = [&](int, int e) { return data[(size_t)b * N + e]; };
   auto st = [&](int, int e, float2 v) { data[(size_t)b * N + e] = v; };
-  fft_block<LOGN, false, false>(lds, tw, threadIdx.x, ld, st);
+  fft_block<PL, false, false>(lds, tw, threadIdx.x, ld, st);
 }
 
 // V1: persistent; twiddles of the passes in HMASK live in registers; everything derived from the
@@ -32,7 +32,7 @@ template <int MINW, unsigned HMASK>
 __global__ __launch_bounds__(256, MINW) void v1(float2 *__restrict__ data, const float2 *__restrict__ tw, uint32_t batch)
 {
   extern __shared__ __attribute__((aligned(16))) float2 lds[];
-  TwRegs<LOGN, HMASK> twr;
+  TwRegs<PL, HMASK> twr;
   twr.tw = tw;
   twr.preload(threadIdx.x);
   for (uint32_t b = blockIdx.x; b < batch; b += gridDim.x) {
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256, MINW) void v1(float2 *__restrict__ data, const
     float2 *__restrict__ p = data + (size_t)b * N;
     auto ld = [&](int, int e) { return p[e]; };
     auto st = [&](int, int e, float2 v) { p[e] = v; };
-    fft_block_tw<LOGN, false, false>(lds, twr, tid, ld, st);
+    fft_block_tw<PL, false, false>(lds, twr, tid, ld, st);
     __syncthreads();
   }
 }
@@ -51,7 +51,7 @@ template <int MINW, unsigned HMASK>
 __global__ __launch_bounds__(256, MINW) void v2(float2 *__restrict__ data, const float2 *__restrict__ tw, uint32_t batch)
 {
   extern __shared__ __attribute__((aligned(16))) float2 lds[];
-  TwRegs<LOGN, HMASK> twr;
+  TwRegs<PL, HMASK> twr;
   twr.tw = tw;
   twr.preload(threadIdx.x);
   uint32_t b = blockIdx.x;
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256, MINW) void v2(float2 *__restrict__ data, const
     }
     float2 *__restrict__ p = data + (size_t)b * N;
     auto st = [&](int, int e, float2 x) { p[e] = x; };
-    fft_block_preloaded<LOGN, false>(v, lds, twr, tid, st);
+    fft_block_preloaded<PL, false>(v, lds, twr, tid, st);
     if (nb >= batch) break;
     b = nb;
     __syncthreads();
