@@ -6,7 +6,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int16, c_int3
 
 __all__ = [
     "lib", "lib_path", "ARM_MATH_SUCCESS", "ARM_MATH_ARGUMENT_ERROR",
-    "arm_cfft_instance_u32_f32", "arm_cfft_instance_f32", "arm_cfft_instance_q15", "arm_cfft_instance_q31", "arm_rfft_fast_instance_f32",
+    "gnss_acq_result", "gnss_top2", "arm_cfft_radix2_instance_f32", "arm_cfft_instance_u32_f32", "arm_cfft_instance_f32", "arm_cfft_instance_q15", "arm_cfft_instance_q31", "arm_rfft_fast_instance_f32",
     "last_error", "EXPORTED_SYMBOLS",
 ]
 
@@ -35,8 +35,23 @@ class arm_cfft_instance_q31(Structure):
                 ("bitRevLength", c_uint16)]
 
 
+class arm_cfft_radix2_instance_f32(Structure):
+    _fields_ = [("fftLen", c_uint16), ("ifftFlag", c_uint8), ("bitReverseFlag", c_uint8), ("pTwiddle", POINTER(c_float)),
+                ("pBitRevTable", POINTER(c_uint16)), ("twidCoefModifier", c_uint16), ("bitRevFactor", c_uint16),
+                ("onebyfftLen", c_float)]
+
+
 class arm_cfft_instance_u32_f32(Structure):
     _fields_ = [("fftLen", c_uint32)]
+
+
+class gnss_acq_result(Structure):
+    _fields_ = [("peak", c_float), ("second", c_float), ("code_phase", c_int32), ("second_phase", c_int32),
+                ("doppler_bin", c_int32), ("prn", c_int32), ("snr_db", c_float), ("code_phase_interp", c_float)]
+
+
+class gnss_top2(Structure):
+    _fields_ = [("val1", c_float), ("idx1", c_int32), ("val2", c_float), ("idx2", c_int32)]
 
 
 class arm_rfft_fast_instance_f32(Structure):
@@ -58,7 +73,10 @@ EXPORTED_SYMBOLS = (
     + ["arm_cfft_init_%d_q31" % n for n in _Q31_SIZES]
     + ["arm_rfft_fast_init_f32", "arm_rfft_fast_f32", "arm_rfft_fast_batch_f32", "arm_rfft_fast_f32_dev"]
     + ["arm_rfft_fast_init_%d_f32" % n for n in _RFFT_SIZES]
+    + ["arm_cfft_radix2_init_f32", "arm_cfft_radix2_f32", "arm_cfft_radix2_batch_f32", "arm_cfft_radix2_f32_dev"]
     + ["arm_cfft_init_u32_f32", "arm_cfft_u32_f32_dev", "arm_cfft_u32_batch_f32"]
+    + ["gnss_acq_plan_create", "gnss_acq_plan_destroy", "gnss_acq_plan_set_peak_separation", "gnss_acq_plan_code_spectra_dev",
+       "gnss_acquire_dev", "gnss_acquire", "gnss_get_code_dev", "gnss_synth_gps_prn_dev", "gnss_find_top2_peaks_dev"]
     + ["arm_fft_mi355_set_device", "arm_fft_mi355_warm", "arm_fft_mi355_last_error",
        "arm_fft_mi355_set_twiddle_rounding", "arm_fft_mi355_version"]
 )
@@ -104,10 +122,26 @@ def _load():
     L.arm_rfft_fast_f32.argtypes, L.arm_rfft_fast_f32.restype = [POINTER(R), c_void_p, c_void_p, u8], None
     L.arm_rfft_fast_batch_f32.argtypes, L.arm_rfft_fast_batch_f32.restype = [POINTER(R), c_void_p, c_void_p, u32, u8], c_int
     L.arm_rfft_fast_f32_dev.argtypes, L.arm_rfft_fast_f32_dev.restype = [POINTER(R), c_void_p, c_void_p, u32, u8, c_void_p], c_int
+    R2 = arm_cfft_radix2_instance_f32
+    L.arm_cfft_radix2_init_f32.argtypes, L.arm_cfft_radix2_init_f32.restype = [POINTER(R2), u16, u8, u8], c_int
+    L.arm_cfft_radix2_f32.argtypes, L.arm_cfft_radix2_f32.restype = [POINTER(R2), c_void_p], None
+    L.arm_cfft_radix2_batch_f32.argtypes, L.arm_cfft_radix2_batch_f32.restype = [POINTER(R2), c_void_p, u32], c_int
+    L.arm_cfft_radix2_f32_dev.argtypes, L.arm_cfft_radix2_f32_dev.restype = [POINTER(R2), c_void_p, u32, c_void_p], c_int
     U = arm_cfft_instance_u32_f32
     L.arm_cfft_init_u32_f32.argtypes, L.arm_cfft_init_u32_f32.restype = [POINTER(U), u32], c_int
     L.arm_cfft_u32_f32_dev.argtypes, L.arm_cfft_u32_f32_dev.restype = [POINTER(U), c_void_p, c_void_p, u32, u8, c_void_p], c_int
     L.arm_cfft_u32_batch_f32.argtypes, L.arm_cfft_u32_batch_f32.restype = [POINTER(U), c_void_p, u32, u8], c_int
+    i32 = c_int32
+    L.gnss_acq_plan_create.argtypes = [POINTER(c_void_p), u32, u32, u32, u32, c_void_p, u32, c_void_p, u32]
+    L.gnss_acq_plan_create.restype = c_int
+    L.gnss_acq_plan_destroy.argtypes, L.gnss_acq_plan_destroy.restype = [c_void_p], None
+    L.gnss_acq_plan_set_peak_separation.argtypes, L.gnss_acq_plan_set_peak_separation.restype = [c_void_p, i32], c_int
+    L.gnss_acq_plan_code_spectra_dev.argtypes, L.gnss_acq_plan_code_spectra_dev.restype = [c_void_p], c_void_p
+    L.gnss_acquire_dev.argtypes, L.gnss_acquire_dev.restype = [c_void_p, c_void_p, u32, u32, u32, c_void_p, c_void_p, c_void_p], c_int
+    L.gnss_acquire.argtypes, L.gnss_acquire.restype = [c_void_p, c_void_p, u32, c_void_p, c_void_p], c_int
+    L.gnss_get_code_dev.argtypes, L.gnss_get_code_dev.restype = [i32, i32, i32, c_void_p], c_int
+    L.gnss_synth_gps_prn_dev.argtypes, L.gnss_synth_gps_prn_dev.restype = [i32, c_float, u32, c_void_p, i32], c_int
+    L.gnss_find_top2_peaks_dev.argtypes, L.gnss_find_top2_peaks_dev.restype = [c_void_p, i32, i32, i32, u32, c_void_p, c_void_p], c_int
     L.arm_fft_mi355_set_device.argtypes, L.arm_fft_mi355_set_device.restype = [c_int], c_int
     L.arm_fft_mi355_warm.argtypes, L.arm_fft_mi355_warm.restype = [c_int, u32], c_int
     L.arm_fft_mi355_last_error.argtypes, L.arm_fft_mi355_last_error.restype = [], c_char_p

@@ -208,6 +208,20 @@ static const uint16_t *host_br_f32(int logn, uint16_t *len)
   return t.data();
 }
 
+// armBitRevTable of the fork's 16384-based legacy scheme (arm_common_tables.h:41, generator
+// CMSIS/CMSIS.cpp:333-354): entry k = 13-bit reversal of k + 1, consumed by arm_bitreversal_f32
+// (arm_bitreversal.c:46-105) with stride bitRevFactor.
+static const uint16_t *host_br_radix2()
+{
+  std::lock_guard<std::mutex> lk(g_mu);
+  static std::vector<uint16_t> t;
+  if (t.empty()) {
+    t.resize(4096);
+    for (uint32_t k = 0; k < 4096; k++) t[k] = (uint16_t)brev(k + 1, 13);
+  }
+  return t.data();
+}
+
 static const uint16_t *host_br_fixed(int logn, uint16_t *len)
 {
   std::lock_guard<std::mutex> lk(g_mu);
@@ -294,6 +308,8 @@ static const float2 *dev_tw_rfft(int logn_real)
   }
   return p;
 }
+
+const float2 *dev_twiddle_f32(int logn) { return dev_tw_f32(logn); }
 
 static const float2 *dev_tw_lo(int logn)
 {
@@ -470,7 +486,7 @@ arm_status arm_cfft_f32_dev(const arm_cfft_instance_f32 *S, float32_t *p, uint32
   if (l < 0) { set_error("arm_cfft_f32_dev: unsupported fftLen %u", (unsigned)S->fftLen); return ARM_MATH_ARGUMENT_ERROR; }
   const float2 *tw = dev_tw_f32(l);
   if (!tw) return ARM_MATH_ARGUMENT_ERROR;
-  hipError_t e = launch_cfft_f32(l, reinterpret_cast<float2 *>(p), tw, batch, ifft != 0, bitrev == 0, (hipStream_t)stream);
+  hipError_t e = launch_cfft_f32(l, reinterpret_cast<float2 *>(p), tw, batch, ifft != 0, bitrev ? 0 : 1, (hipStream_t)stream);
   return hip_ok(e, "cfft_f32 launch") ? ARM_MATH_SUCCESS : ARM_MATH_ARGUMENT_ERROR;
 }
 
@@ -486,6 +502,59 @@ void arm_cfft_f32(const arm_cfft_instance_f32 *S, float32_t *p1, uint8_t ifftFla
   if (arm_cfft_batch_f32(S, p1, 1, ifftFlag, bitReverseFlag) != ARM_MATH_SUCCESS) {
     fprintf(stderr, "libarmfft_mi355: arm_cfft_f32 cannot run (%s)\n", t_err);
     abort();  // a void entry point has no other way to refuse to return wrong data
+  }
+}
+
+// ---------------- f32 complex, deprecated radix-2 API (what fft_c32 calls, CMSIS/CMSIS.cpp:218-234) ----------------
+// arm_cfft_radix2_init_f32.c:64-218: the fields are written BEFORE the length switch, so an
+// unsupported length still leaves fftLen/flags/pTwiddle set and returns ARM_MATH_ARGUMENT_ERROR.
+arm_status arm_cfft_radix2_init_f32(arm_cfft_radix2_instance_f32 *S, uint16_t fftLen, uint8_t ifftFlag, uint8_t bitReverseFlag)
+{
+  if (!S) return ARM_MATH_ARGUMENT_ERROR;
+  S->fftLen = fftLen;
+  S->pTwiddle = host_tw_f32(kMaxLog);  // the shared 16384-entry table, indexed with twidCoefModifier
+  S->ifftFlag = ifftFlag;
+  S->bitReverseFlag = bitReverseFlag;
+  int l = cfft_log(fftLen);
+  if (l < 0) return ARM_MATH_ARGUMENT_ERROR;
+  const uint16_t mod = (uint16_t)(16384u >> l);
+  S->twidCoefModifier = mod;
+  S->bitRevFactor = mod;
+  S->pBitRevTable = host_br_radix2() + (mod - 1);
+  S->onebyfftLen = 1.0f / (float)fftLen;
+  return ARM_MATH_SUCCESS;
+}
+
+arm_status arm_cfft_radix2_f32_dev(const arm_cfft_radix2_instance_f32 *S, float32_t *p, uint32_t batch, void *stream)
+{
+  if (!S || !p) { set_error("arm_cfft_radix2_f32_dev: null argument"); return ARM_MATH_ARGUMENT_ERROR; }
+  int l = cfft_log(S->fftLen);
+  if (l < 0) { set_error("arm_cfft_radix2_f32_dev: unsupported fftLen %u", (unsigned)S->fftLen); return ARM_MATH_ARGUMENT_ERROR; }
+  const float2 *tw = dev_tw_f32(l);
+  if (!tw) return ARM_MATH_ARGUMENT_ERROR;
+  // bitReverseFlag == 0 leaves the radix-2 DIF order: plain bit reversal (arm_cfft_radix2_f32.c:64-88)
+  hipError_t e = launch_cfft_f32(l, reinterpret_cast<float2 *>(p), tw, batch, S->ifftFlag != 0, S->bitReverseFlag ? 0 : 2,
+                                 (hipStream_t)stream);
+  return hip_ok(e, "cfft_radix2_f32 launch") ? ARM_MATH_SUCCESS : ARM_MATH_ARGUMENT_ERROR;
+}
+
+static arm_status radix2_dev_adapter(const arm_cfft_radix2_instance_f32 *S, float32_t *p, uint32_t batch, uint8_t, uint8_t, void *stream)
+{
+  return arm_cfft_radix2_f32_dev(S, p, batch, stream);
+}
+
+arm_status arm_cfft_radix2_batch_f32(const arm_cfft_radix2_instance_f32 *S, float32_t *p, uint32_t batch)
+{
+  if (!S || cfft_log(S->fftLen) < 0) { set_error("arm_cfft_radix2_batch_f32: unsupported instance"); return ARM_MATH_ARGUMENT_ERROR; }
+  return host_batch<arm_cfft_radix2_instance_f32, float32_t>(S, p, batch, 2 * (size_t)S->fftLen, radix2_dev_adapter, 0, 0);
+}
+
+void arm_cfft_radix2_f32(const arm_cfft_radix2_instance_f32 *S, float32_t *pSrc)
+{
+  if (!S || cfft_log(S->fftLen) < 0) return;
+  if (arm_cfft_radix2_batch_f32(S, pSrc, 1) != ARM_MATH_SUCCESS) {
+    fprintf(stderr, "libarmfft_mi355: arm_cfft_radix2_f32 cannot run (%s)\n", t_err);
+    abort();
   }
 }
 
@@ -509,7 +578,7 @@ arm_status arm_cfft_u32_f32_dev(const arm_cfft_instance_u32_f32 *S, float32_t *p
   if (l >= kMinLog && l <= kMaxLog) {
     const float2 *tw = dev_tw_f32(l);
     if (!tw) return ARM_MATH_ARGUMENT_ERROR;
-    return hip_ok(launch_cfft_f32(l, reinterpret_cast<float2 *>(p), tw, batch, ifft != 0, false, (hipStream_t)stream), "cfft_f32 launch")
+    return hip_ok(launch_cfft_f32(l, reinterpret_cast<float2 *>(p), tw, batch, ifft != 0, 0, (hipStream_t)stream), "cfft_f32 launch")
                ? ARM_MATH_SUCCESS : ARM_MATH_ARGUMENT_ERROR;
   }
   if (l < kMinLargeLog || l > kMaxLargeLog) { set_error("arm_cfft_u32_f32_dev: unsupported fftLen %u", S->fftLen); return ARM_MATH_ARGUMENT_ERROR; }

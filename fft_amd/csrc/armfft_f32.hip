@@ -41,7 +41,7 @@ template <> struct Tune<12> { static constexpr unsigned HMASK = 6; static conste
 
 template <int LOGN, bool INV>
 __global__ __launch_bounds__(Plan<LOGN>::T, Tune<LOGN>::MINW) void cfft_f32_kernel(float2 *__restrict__ data, const float2 *__restrict__ tw,
-                                                                                 uint32_t batch, uint32_t ngroups, int scramble)
+                                                                                 uint32_t batch, uint32_t ngroups, int order)
 {
   using PL = Plan<LOGN>;
   extern __shared__ __attribute__((aligned(16))) float2 lds[];
@@ -63,7 +63,8 @@ __global__ __launch_bounds__(Plan<LOGN>::T, Tune<LOGN>::MINW) void cfft_f32_kern
     };
     auto st = [&](int t, int e, float2 v) {
       if (INV) v = make_float2(v.x * inv_n, -v.y * inv_n);
-      if (scramble) e = scrambled_pos<LOGN>(e);
+      if (order == 1) e = scrambled_pos<LOGN>(e);
+      if (order == 2) e = (int)(__brev((unsigned)e) >> (32 - LOGN));
       if (t0 + t < batch) p[t * PL::N + e] = v;
     };
     fft_block_tw<PL, false, false>(lds, twr, tid, ld, st);
@@ -194,7 +195,7 @@ static dim3 grid_for(uint32_t ngroups)
 }
 
 template <int LOGN, bool INV>
-static hipError_t launch_cfft_one(float2 *data, const float2 *tw, uint32_t batch, bool scramble, hipStream_t stream)
+static hipError_t launch_cfft_one(float2 *data, const float2 *tw, uint32_t batch, int order, hipStream_t stream)
 {
   using PL = Plan<LOGN>;
   static bool attr_done[16] = {false};
@@ -212,17 +213,17 @@ static hipError_t launch_cfft_one(float2 *data, const float2 *tw, uint32_t batch
     const uint32_t resident = (uint32_t)Tune<LOGN>::WGPCU * (uint32_t)cu_count(dev);
     if (ngroups > resident) grid = dim3(resident, 1, 1);
   }
-  kern<<<grid, PL::T, PL::LDS_BYTES, stream>>>(data, tw, batch, ngroups, scramble ? 1 : 0);
+  kern<<<grid, PL::T, PL::LDS_BYTES, stream>>>(data, tw, batch, ngroups, order);
   return hipGetLastError();
 }
 
-hipError_t launch_cfft_f32(int logn, float2 *data, const float2 *tw, uint32_t batch, bool inverse, bool scramble,
+hipError_t launch_cfft_f32(int logn, float2 *data, const float2 *tw, uint32_t batch, bool inverse, int order,
                            hipStream_t stream)
 {
   if (batch == 0) return hipSuccess;
   switch (logn) {
 #define C(L) \
-  case L: return inverse ? launch_cfft_one<L, true>(data, tw, batch, scramble, stream) : launch_cfft_one<L, false>(data, tw, batch, scramble, stream);
+  case L: return inverse ? launch_cfft_one<L, true>(data, tw, batch, order, stream) : launch_cfft_one<L, false>(data, tw, batch, order, stream);
     C(4) C(5) C(6) C(7) C(8) C(9) C(10) C(11) C(12) C(13) C(14)
 #undef C
   }

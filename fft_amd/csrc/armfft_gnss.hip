@@ -1,0 +1,649 @@
+// armfft_gnss.hip -- GNSS code-phase/Doppler acquisition for gfx950, fused around the LDS FFT core.
+//
+// Replaces the fork's per-cell recipe (read_ors, CMSIS/CMSIS.cpp:706-737: synth_gps_prn replica ->
+// fft_c32(replica), fft_c32(signal), S*conj(R) -> fft_c32 inverse -> find_top2_peaks_cplx;
+// coherent fold CMSIS.cpp:1154-1169) with ONE kernel per acquisition:
+//
+//   workgroup (scene, Doppler bin d):
+//     wipe-off + fold   z[m] = u_d[m] * sum_b w_d[b] * x[b*spm + m]        (rows a15, a16)
+//                       u_d[m] = e^{-j 2 pi f_d m / FS}, w_d[b] = e^{-j 2 pi f_d b spm / FS}
+//     Z = FFT(z zero-padded to fft_len)                                    (a2/a9/a13)
+//     for every PRN p:  y = IFFT(Z * conj(C_p)),  |y|                      (a12)
+//                       top-2 peaks (separation pk_sep), SNR, 3-point interpolation   (a14)
+//   C_p = FFT(C/A code p, sample-and-hold, zero Doppler), computed once per plan (a10, a11).
+//
+// Z stays in registers across the PRN loop, the code spectra (n_prn x fft_len x 8 B, 1 MiB for
+// 32 PRNs at 4096) are L2-resident, the correlation surface never leaves the CU: per (PRN,
+// Doppler) row only the 32-byte result tuple goes to HBM.  Bound: LDS bandwidth / fp32 VALU.
+//
+// find_top2_peaks_cplx (gnss_codes.c:1144-1166) is a sequential scan whose second peak depends on
+// which index was the running best when each sample was seen; top2_scan() below reproduces it
+// exactly (values and indices, ties included) with a workgroup prefix scan.
+#include <mutex>
+#include <vector>
+
+#include "armfft_internal.h"
+#include "fft_core_f32.hpp"
+
+namespace armfft {
+
+// ------------------------------------------------------------------------------------------
+// GPS L1 C/A code (getCode, gnss_codes.c:969-1030)
+// ------------------------------------------------------------------------------------------
+// G2 tap pairs (0-based stage indices) for PRN 1..37, gnss_codes.c:971-1008
+__constant__ int8_t k_g2_taps[37][2] = {
+    {1, 5}, {2, 6}, {3, 7}, {4, 8}, {0, 8}, {1, 9}, {0, 7}, {1, 8}, {2, 9}, {1, 2}, {2, 3}, {4, 5}, {5, 6},
+    {6, 7}, {7, 8}, {8, 9}, {0, 3}, {1, 4}, {2, 5}, {3, 6}, {4, 7}, {5, 8}, {0, 2}, {3, 5}, {4, 6}, {5, 7},
+    {6, 8}, {7, 9}, {0, 5}, {1, 6}, {2, 7}, {3, 8}, {4, 9}, {3, 9}, {0, 6}, {1, 7}, {3, 9}};
+
+constexpr int kCodeLen = 1023;
+
+// one sequence per workgroup at every size: N/16 threads
+template <int LOGN>
+using GPlan = Plan<LOGN, (1 << LOGN) / 16>;
+
+// chips[p][i] (+1 / -1 as int8), i < 1023.  One workgroup per PRN: thread 0 clocks the two 10-stage
+// registers (all-ones start; G1 feedback stages {2,9}, G2 {1,2,5,7,8,9}) and records G1's output
+// and G2's whole state per step, then all threads combine the PRN's two G2 taps.
+__global__ void gnss_code_kernel(const int32_t *__restrict__ prns, int8_t *__restrict__ chips)
+{
+  __shared__ uint16_t g2_state[kCodeLen];
+  __shared__ uint8_t g1_out[kCodeLen];
+  const int prn = prns[blockIdx.x];
+  if (threadIdx.x == 0) {
+    uint32_t g1 = 0x3FF, g2 = 0x3FF;  // bit j = stage j
+    for (int i = 0; i < kCodeLen; i++) {
+      g1_out[i] = (g1 >> 9) & 1;
+      g2_state[i] = (uint16_t)g2;
+      const uint32_t f1 = ((g1 >> 2) ^ (g1 >> 9)) & 1;
+      const uint32_t f2 = ((g2 >> 1) ^ (g2 >> 2) ^ (g2 >> 5) ^ (g2 >> 7) ^ (g2 >> 8) ^ (g2 >> 9)) & 1;
+      g1 = ((g1 << 1) | f1) & 0x3FF;
+      g2 = ((g2 << 1) | f2) & 0x3FF;
+    }
+  }
+  __syncthreads();
+  const int s0 = k_g2_taps[prn - 1][0], s1 = k_g2_taps[prn - 1][1];
+  for (int i = threadIdx.x; i < kCodeLen; i += blockDim.x) {
+    const int val = g1_out[i] ^ ((g2_state[i] >> s0) & 1) ^ ((g2_state[i] >> s1) & 1);
+    chips[(size_t)blockIdx.x * kCodeLen + i] = val ? 1 : -1;  // logic 1 -> +1 (:1016-1018)
+  }
+}
+
+// probe of getCode: out[n] = chip[(n / spc) mod 1023], n < num * spc
+__global__ void gnss_expand_code_kernel(const int8_t *__restrict__ chips, int32_t *__restrict__ out, int total, int spc)
+{
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n < total) out[n] = chips[(n / spc) % kCodeLen];
+}
+
+// probe of synth_gps_prn / mix_prn (gnss_codes.c:1032-1071): replica[n] = code[n] e^{j 2 pi f n / FS}
+__global__ void gnss_replica_kernel(const int8_t *__restrict__ chips, float2 *__restrict__ out, int size, int spc, double doppler,
+                                    double phase_cycles)
+{
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= size) return;
+  const double FS = 1.023e6 * spc;
+  double cyc = doppler * (double)n / FS + phase_cycles;
+  cyc -= floor(cyc);
+  double s, c;
+  sincospi(2.0 * cyc, &s, &c);
+  const double a = (double)chips[(n / spc) % kCodeLen];
+  out[n] = make_float2((float)(a * c), (float)(a * s));
+}
+
+// ------------------------------------------------------------------------------------------
+// exact parallel form of find_top2_peaks (gnss_codes.c:1144-1190)
+// ------------------------------------------------------------------------------------------
+// Sequential rule, per sample x at index m with state (v1, i1, v2, i2):
+//   x >= v1 : if (i1 != -1 && |m - i1| > sep) (v2, i2) = (v1, i1);  (v1, i1) = (x, m)
+//   else if x > v2 && |m - i1| > sep : (v2, i2) = (x, m)
+// => (v1, i1) = maximum, LAST index on ties;  the state (v1, i1) seen by sample m is the prefix
+// maximum before m (last index on ties), so every sample yields at most one candidate for the
+// second peak: (A) a record hands down the previous record if that lies > sep away, (B) a
+// non-record more than sep away from the current record offers itself.  v2 = the largest
+// candidate; on equal values an (A) candidate always overwrites (latest wins), a (B) candidate
+// only takes over when strictly larger (earliest wins) -- encoded in the key below.
+struct PrefixMax {
+  float v;
+  int i;
+};
+__device__ __forceinline__ PrefixMax pm_combine(PrefixMax earlier, PrefixMax later) { return later.v >= earlier.v ? later : earlier; }
+
+struct Top2 {
+  float v1, v2;
+  int i1, i2;
+  double sum;  // sum of all n magnitudes
+};
+
+constexpr float kNoPeak = -1e10f;  // the reference's initial value (gnss_codes.c:1148)
+
+// order-preserving map float -> uint32 (find_top2_peaks_real may see negative samples)
+__device__ __forceinline__ unsigned ord_bits(float f)
+{
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord_float(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k); }
+
+// T threads, thread tid owns samples [tid*CH, tid*CH + CH) of mag(m) (m < n valid).  `xch` = LDS
+// scratch of >= 3 * (T/64) * 8 + 16 bytes not aliased with what mag() reads.  All threads return the result.
+template <int T, int CH, class Mag>
+__device__ __forceinline__ Top2 top2_scan(Mag mag, int n, int sep, int tid, void *xch)
+{
+  constexpr int NW = (T + 63) / 64;
+  const int lane = tid & 63, wv = tid >> 6;
+  float x[CH];
+  PrefixMax loc{kNoPeak, -1};
+  double sum = 0.0;
+#pragma unroll
+  for (int c = 0; c < CH; c++) {
+    const int m = tid * CH + c;
+    x[c] = m < n ? mag(m) : kNoPeak;
+    if (m < n) {
+      sum += (double)x[c];
+      loc = pm_combine(loc, PrefixMax{x[c], m});
+    }
+  }
+  // inclusive scan of the per-thread maxima over the wave, then over the waves
+  PrefixMax inc = loc;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    PrefixMax o{__shfl_up(inc.v, off), __shfl_up(inc.i, off)};
+    if (lane >= off) inc = pm_combine(o, inc);
+  }
+  PrefixMax exc{__shfl_up(inc.v, 1), __shfl_up(inc.i, 1)};
+  if (lane == 0) exc = PrefixMax{kNoPeak, -1};
+  PrefixMax *wtot = reinterpret_cast<PrefixMax *>(xch);                          // [NW]
+  unsigned long long *wkey = reinterpret_cast<unsigned long long *>(wtot + NW);  // [NW]
+  double *wsum = reinterpret_cast<double *>(wkey + NW);                          // [NW]
+  if (lane == 63 || tid == T - 1) wtot[wv] = inc;
+  __syncthreads();
+  PrefixMax before{kNoPeak, -1}, total{kNoPeak, -1};
+#pragma unroll
+  for (int w = 0; w < NW; w++) {
+    const PrefixMax t = wtot[w];
+    if (w < wv) before = pm_combine(before, t);
+    total = pm_combine(total, t);
+  }
+  PrefixMax run = pm_combine(before, exc);  // state (v1, i1) seen by this thread's first sample
+
+  // walk the chunk, collect the best second-peak candidate as an ordered key
+  //   key = ordered value bits << 32 | A << 31 | order << 15 | index
+  //   A: order = position of the record that hands down;  B: order = 32767 - m (earliest wins)
+  unsigned long long key = 0;
+#pragma unroll
+  for (int c = 0; c < CH; c++) {
+    const int m = tid * CH + c;
+    if (m < n) {
+      if (x[c] >= run.v) {
+        if (run.i != -1 && abs(m - run.i) > sep) {
+          const unsigned long long k = ((unsigned long long)ord_bits(run.v) << 32) | (1ull << 31) |
+                                       ((unsigned long long)m << 15) | (unsigned long long)run.i;
+          key = k > key ? k : key;
+        }
+        run = PrefixMax{x[c], m};
+      } else if (run.i != -1 && abs(m - run.i) > sep) {
+        const unsigned long long k = ((unsigned long long)ord_bits(x[c]) << 32) | ((unsigned long long)(32767 - m) << 15) |
+                                     (unsigned long long)m;
+        key = k > key ? k : key;
+      }
+    }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const unsigned long long o = __shfl_xor(key, off);
+    key = o > key ? o : key;
+    sum += __shfl_xor(sum, off);
+  }
+  if (lane == 0) {
+    wkey[wv] = key;
+    wsum[wv] = sum;
+  }
+  __syncthreads();
+  key = 0;
+  sum = 0.0;
+#pragma unroll
+  for (int w = 0; w < NW; w++) {
+    const unsigned long long o = wkey[w];
+    key = o > key ? o : key;
+    sum += wsum[w];
+  }
+  Top2 r;
+  r.v1 = total.v;
+  r.i1 = total.i;
+  r.sum = sum;
+  if (key) {
+    r.v2 = ord_float((unsigned)(key >> 32));
+    r.i2 = (int)(key & 0x7FFF);
+  } else {
+    r.v2 = kNoPeak;
+    r.i2 = -1;
+  }
+  return r;
+}
+
+// compute_snr_cplx (gnss_codes.c:1110-1125) and InterpolateCodePhase (:1096-1108) on the finished row
+template <class Mag>
+__device__ __forceinline__ void finish_row(const Top2 &t, Mag mag, int n, int dop_bin, int prn, gnss_acq_result *out)
+{
+  double off = t.sum;
+  for (int i = t.i1 - 2; i <= t.i1 + 2; i++)
+    if (i >= 0 && i < n) off -= (double)mag(i);
+  const double mean = off / (double)(n - 5);
+  const double early = (double)mag((t.i1 + n - 1) % n), late = (double)mag((t.i1 + 1) % n), prompt = (double)t.v1;
+  double xi, interp;
+  if (late > early) {
+    xi = 0.5 * (late - early) / (prompt - early);
+    interp = (double)t.i1 + (xi / 3.0) * (2.0 * xi + 2.0);
+  } else {
+    xi = 0.5 * (late - early) / (prompt - late);
+    interp = (double)t.i1 + (xi / 3.0) * (-2.0 * xi + 2.0);
+  }
+  gnss_acq_result r;
+  r.peak = t.v1;
+  r.second = t.v2;
+  r.code_phase = t.i1;
+  r.second_phase = t.i2;
+  r.doppler_bin = dop_bin;
+  r.prn = prn;
+  r.snr_db = (float)(10.0 * log10(prompt / mean));
+  r.code_phase_interp = (float)interp;
+  *out = r;
+}
+
+// probe: find_top2_peaks_{real,cplx} on `batch` rows of n samples in global memory
+template <bool CPLX>
+__global__ __launch_bounds__(256) void gnss_top2_kernel(const float *__restrict__ data, int n, int sep, gnss_top2 *__restrict__ out)
+{
+  __shared__ __attribute__((aligned(16))) unsigned char xch[3 * 4 * 8 + 16];
+  const float *row = data + (size_t)blockIdx.x * n * (CPLX ? 2 : 1);
+  auto mag = [&](int m) -> float {
+    if (CPLX) {
+      const float re = row[2 * m], im = row[2 * m + 1];
+      return sqrtf(re * re + im * im);
+    }
+    return row[m];
+  };
+  const Top2 t = top2_scan<256, 64>(mag, n, sep, threadIdx.x, xch);  // n <= 16384
+  if (threadIdx.x == 0) {
+    gnss_top2 r;
+    r.val1 = t.v1;
+    r.idx1 = t.i1;
+    r.val2 = t.v2;
+    r.idx2 = t.i2;
+    out[blockIdx.x] = r;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// code spectra: C_p = FFT(code p sampled at spc samples per chip, spm samples, zero-padded)
+// ------------------------------------------------------------------------------------------
+template <int LOGN>
+__global__ __launch_bounds__(GPlan<LOGN>::T) void gnss_code_spectrum_kernel(const int8_t *__restrict__ chips,
+                                                                                             float2 *__restrict__ spectra,
+                                                                                             const float2 *__restrict__ tw, int spm, int spc)
+{
+  using PL = GPlan<LOGN>;
+  extern __shared__ __attribute__((aligned(16))) float2 lds[];
+  const int8_t *c = chips + (size_t)blockIdx.x * kCodeLen;
+  float2 *dst = spectra + (size_t)blockIdx.x * PL::N;
+  auto ld = [&](int, int e) -> float2 { return make_float2(e < spm ? (float)c[(e / spc) % kCodeLen] : 0.f, 0.f); };
+  auto st = [&](int, int k, float2 v) { dst[k] = v; };
+  fft_block<PL, false, false>(lds, tw, threadIdx.x, ld, st);
+}
+
+// ------------------------------------------------------------------------------------------
+// the fused acquisition kernel
+// ------------------------------------------------------------------------------------------
+constexpr int kMaxMs = 64;
+
+template <int LOGN>
+__global__ __launch_bounds__(GPlan<LOGN>::T, GPlan<LOGN>::T >= 1024 ? 4 : 3) void gnss_acquire_kernel(
+    const float2 *__restrict__ signal,   // [n_scenes][n_ms * spm]
+    const float2 *__restrict__ spectra,  // [n_prn][N]
+    const float2 *__restrict__ tw, const float *__restrict__ dopplers, const int32_t *__restrict__ prns, int n_prn, int n_dop,
+    int dop_begin, int n_ms, int spm, int spc, int sep,
+    gnss_acq_result *__restrict__ all)   // [n_scenes][n_prn][n_dop]
+{
+  using PL = GPlan<LOGN>;
+  constexpr int N = PL::N, T = PL::T;
+  extern __shared__ __attribute__((aligned(16))) float2 lds[];
+  // LDS map: [0, LDS_ELEMS) FFT image (the magnitude row aliases its head), then the exchange
+  // scratch of top2_scan, then the per-block phasors w[b]
+  unsigned char *xch = reinterpret_cast<unsigned char *>(lds + PL::LDS_ELEMS);
+  float2 *wblk = reinterpret_cast<float2 *>(xch + 3 * ((T + 63) / 64) * 8 + 16);
+  float *magl = reinterpret_cast<float *>(lds);
+  auto mag_idx = [](int m) { return m + ((m >> 4) << 2); };  // 16 floats + 4 pad: conflict-free 16-byte chunk reads
+
+  const int tid = threadIdx.x;
+  const int d = dop_begin + blockIdx.x, scene = blockIdx.y;
+  const double FS = 1.023e6 * (double)spc;
+  const double fd = (double)dopplers[d];
+  const float2 *__restrict__ sig = signal + (size_t)scene * n_ms * spm;
+
+  if (tid < n_ms) {
+    double cyc = fd * (double)tid * (double)spm / FS;
+    cyc -= floor(cyc);
+    double s, c;
+    sincospi(2.0 * cyc, &s, &c);
+    wblk[tid] = make_float2((float)c, (float)(-s));
+  }
+  __syncthreads();
+
+  // ---- wipe-off + coherent fold into LDS (one point at a time: the double-precision phase is
+  //      register-hungry), then the forward FFT, spectrum back to LDS in natural order ----
+#pragma unroll 1
+  for (int e = tid; e < N; e += T) {
+    float2 acc = make_float2(0.f, 0.f);
+    if (e < spm) {
+#pragma unroll 2
+      for (int b = 0; b < n_ms; b++) {
+        const float2 xv = sig[b * spm + e];
+        const float2 w = wblk[b];
+        acc.x += xv.x * w.x - xv.y * w.y;
+        acc.y += xv.x * w.y + xv.y * w.x;
+      }
+      double cyc = fd * (double)e / FS;
+      cyc -= floor(cyc);
+      double s, c;
+      sincospi(2.0 * cyc, &s, &c);
+      acc = cmul(acc, make_float2((float)c, (float)(-s)));
+    }
+    lds[PL::idx(0, e)] = acc;
+  }
+  __syncthreads();
+  {
+    auto ld = [&](int, int e) -> float2 { return lds[PL::idx(0, e)]; };
+    auto st = [&](int, int k, float2 v) { lds[PL::idx(0, k)] = v; };
+    fft_block<PL, true, true>(lds, tw, tid, ld, st);
+  }
+  __syncthreads();
+  // conj(Z) in the order the first pass consumes its inputs
+  float2 zc[16];
+  for_each_first_pass_input<PL>(tid, [&](int slot, int, int e) {
+    const float2 z = lds[PL::idx(0, e)];
+    zc[slot] = make_float2(z.x, -z.y);
+  });
+  __syncthreads();
+
+  const float inv_n = 1.0f / (float)N;
+  for (int p = 0; p < n_prn; p++) {
+    int lt = tid;
+    asm volatile("" : "+v"(lt));  // per-thread twiddle/LDS address math stays inside the loop (else: spills)
+    const float2 *__restrict__ cs = spectra + (size_t)p * N;
+    // IFFT(Z conj(C)) = conj(FFT(conj(Z) C)) / N; only the magnitude is used
+    float2 v[16];
+    for_each_first_pass_input<PL>(lt, [&](int slot, int, int e) { v[slot] = cmul(zc[slot], cs[e]); });
+    auto st = [&](int, int k, float2 y) {
+      const float re = y.x * inv_n, im = y.y * inv_n;
+      magl[mag_idx(k)] = sqrtf(re * re + im * im);
+    };
+    TwTable twt{tw};
+    fft_block_preloaded<PL, true>(v, lds, twt, lt, st);
+    __syncthreads();
+    auto mag = [&](int m) -> float { return magl[mag_idx(m)]; };
+    const Top2 t = top2_scan<T, 16>(mag, N, sep, lt, xch);
+    if (lt == 0) finish_row(t, mag, N, d, prns[p], all + ((size_t)scene * n_prn + p) * n_dop + d);
+    __syncthreads();  // the row is dead: the next IFFT may overwrite it
+  }
+}
+
+// best Doppler bin per (scene, PRN): largest peak, lowest bin on ties (strict > scanning upwards)
+__global__ void gnss_best_kernel(const gnss_acq_result *__restrict__ all, gnss_acq_result *__restrict__ best, int rows, int n_dop,
+                                 int dop_begin, int dop_end)
+{
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const gnss_acq_result *a = all + (size_t)r * n_dop;
+  gnss_acq_result b = a[dop_begin];
+  for (int d = dop_begin + 1; d < dop_end; d++)
+    if (a[d].peak > b.peak) b = a[d];
+  best[r] = b;
+}
+
+// ------------------------------------------------------------------------------------------
+// host side: plan + C ABI
+// ------------------------------------------------------------------------------------------
+}  // namespace armfft
+
+using namespace armfft;
+
+struct gnss_acq_plan {
+  int device = 0;
+  int logn = 0, fft_len = 0, spm = 0, n_ms = 0, spc = 0, n_prn = 0, n_dop = 0, pk_sep = 3;
+  int32_t *prns_dev = nullptr;
+  float *dops_dev = nullptr;
+  int8_t *chips_dev = nullptr;
+  float2 *spectra_dev = nullptr;
+  const float2 *tw = nullptr;
+  // staging for the host-pointer entry point
+  float2 *sig_stage = nullptr;
+  gnss_acq_result *all_stage = nullptr, *best_stage = nullptr;
+  size_t stage_scenes = 0;
+  std::mutex mu;
+};
+
+namespace {
+
+template <int LOGN>
+hipError_t launch_spectrum(const gnss_acq_plan *pl, hipStream_t s)
+{
+  using PL = GPlan<LOGN>;
+  auto k = gnss_code_spectrum_kernel<LOGN>;
+  hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PL::LDS_BYTES);
+  if (e != hipSuccess) return e;
+  k<<<pl->n_prn, PL::T, PL::LDS_BYTES, s>>>(pl->chips_dev, pl->spectra_dev, pl->tw, pl->spm, pl->spc);
+  return hipGetLastError();
+}
+
+template <int LOGN>
+hipError_t launch_acquire(const gnss_acq_plan *pl, const float2 *sig, uint32_t n_scenes, int d0, int d1, gnss_acq_result *all,
+                          hipStream_t s)
+{
+  using PL = GPlan<LOGN>;
+  const size_t lds = PL::LDS_BYTES + 3 * ((PL::T + 63) / 64) * 8 + 16 + kMaxMs * sizeof(float2);
+  auto k = gnss_acquire_kernel<LOGN>;
+  hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  k<<<dim3(d1 - d0, n_scenes), PL::T, lds, s>>>(sig, pl->spectra_dev, pl->tw, pl->dops_dev, pl->prns_dev, pl->n_prn, pl->n_dop, d0,
+                                                pl->n_ms, pl->spm, pl->spc, pl->pk_sep, all);
+  return hipGetLastError();
+}
+
+#define GNSS_DISPATCH(fn, logn, ...)                 \
+  [&]() -> hipError_t {                              \
+    switch (logn) {                                  \
+      case 10: return fn<10>(__VA_ARGS__);           \
+      case 11: return fn<11>(__VA_ARGS__);           \
+      case 12: return fn<12>(__VA_ARGS__);           \
+      case 13: return fn<13>(__VA_ARGS__);           \
+      case 14: return fn<14>(__VA_ARGS__);           \
+    }                                                \
+    return hipErrorInvalidValue;                     \
+  }()
+
+bool plan_on_device(const gnss_acq_plan *pl, const char *who)
+{
+  int dev = -1;
+  if (!hip_ok(hipGetDevice(&dev), "hipGetDevice")) return false;
+  if (dev != pl->device) {
+    set_error("%s: the plan was created on device %d, the current device is %d", who, pl->device, dev);
+    return false;
+  }
+  return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+void gnss_acq_plan_destroy(gnss_acq_plan *pl)
+{
+  if (!pl) return;
+  (void)hipFree(pl->prns_dev);
+  (void)hipFree(pl->dops_dev);
+  (void)hipFree(pl->chips_dev);
+  (void)hipFree(pl->spectra_dev);
+  (void)hipFree(pl->sig_stage);
+  (void)hipFree(pl->all_stage);
+  (void)hipFree(pl->best_stage);
+  delete pl;
+}
+
+arm_status gnss_acq_plan_create(gnss_acq_plan **out, uint32_t fft_len, uint32_t samples_per_ms, uint32_t n_ms,
+                                uint32_t samples_per_chip, const int32_t *prns, uint32_t n_prn, const float *dopplers_hz,
+                                uint32_t n_dop)
+{
+  if (!out || !prns || !dopplers_hz) { set_error("gnss_acq_plan_create: null argument"); return ARM_MATH_ARGUMENT_ERROR; }
+  *out = nullptr;
+  int logn = -1;
+  for (int l = 10; l <= 14; l++)
+    if (fft_len == (1u << l)) logn = l;
+  if (logn < 0) { set_error("gnss_acq_plan_create: fft_len %u is not a power of two in 1024..16384", fft_len); return ARM_MATH_ARGUMENT_ERROR; }
+  if (samples_per_ms == 0 || samples_per_ms > fft_len || n_ms == 0 || n_ms > (uint32_t)kMaxMs || samples_per_chip == 0 ||
+      n_prn == 0 || n_prn > 64 || n_dop == 0 || n_dop > 32768) {
+    set_error("gnss_acq_plan_create: bad geometry (samples_per_ms %u <= fft_len, n_ms 1..%d, n_prn 1..64, n_dop 1..32768)",
+              samples_per_ms, kMaxMs);
+    return ARM_MATH_ARGUMENT_ERROR;
+  }
+  for (uint32_t i = 0; i < n_prn; i++)
+    if (prns[i] < 1 || prns[i] > 37) { set_error("gnss_acq_plan_create: PRN %d outside 1..37", prns[i]); return ARM_MATH_ARGUMENT_ERROR; }
+  gnss_acq_plan *pl = new gnss_acq_plan;
+  if (!hip_ok(hipGetDevice(&pl->device), "hipGetDevice")) { delete pl; return ARM_MATH_ARGUMENT_ERROR; }
+  pl->logn = logn; pl->fft_len = (int)fft_len; pl->spm = (int)samples_per_ms; pl->n_ms = (int)n_ms; pl->spc = (int)samples_per_chip;
+  pl->n_prn = (int)n_prn; pl->n_dop = (int)n_dop;
+  pl->tw = dev_twiddle_f32(logn);
+  bool ok = pl->tw != nullptr;
+  ok = ok && hip_ok(hipMalloc((void **)&pl->prns_dev, sizeof(int32_t) * n_prn), "hipMalloc(prns)");
+  ok = ok && hip_ok(hipMalloc((void **)&pl->dops_dev, sizeof(float) * n_dop), "hipMalloc(dopplers)");
+  ok = ok && hip_ok(hipMalloc((void **)&pl->chips_dev, (size_t)n_prn * kCodeLen), "hipMalloc(chips)");
+  ok = ok && hip_ok(hipMalloc((void **)&pl->spectra_dev, sizeof(float2) * (size_t)n_prn * fft_len), "hipMalloc(code spectra)");
+  ok = ok && hip_ok(hipMemcpy(pl->prns_dev, prns, sizeof(int32_t) * n_prn, hipMemcpyHostToDevice), "hipMemcpy(prns)");
+  ok = ok && hip_ok(hipMemcpy(pl->dops_dev, dopplers_hz, sizeof(float) * n_dop, hipMemcpyHostToDevice), "hipMemcpy(dopplers)");
+  if (ok) {
+    gnss_code_kernel<<<n_prn, 256, 0, nullptr>>>(pl->prns_dev, pl->chips_dev);
+    ok = hip_ok(hipGetLastError(), "gnss_code_kernel") && hip_ok(GNSS_DISPATCH(launch_spectrum, logn, pl, nullptr), "code spectra") &&
+         hip_ok(hipStreamSynchronize(nullptr), "plan synchronise");
+  }
+  if (!ok) { gnss_acq_plan_destroy(pl); return ARM_MATH_ARGUMENT_ERROR; }
+  *out = pl;
+  return ARM_MATH_SUCCESS;
+}
+
+arm_status gnss_acq_plan_set_peak_separation(gnss_acq_plan *pl, int32_t pk_sep)
+{
+  if (!pl || pk_sep < 0) { set_error("gnss_acq_plan_set_peak_separation: bad argument"); return ARM_MATH_ARGUMENT_ERROR; }
+  pl->pk_sep = pk_sep;
+  return ARM_MATH_SUCCESS;
+}
+
+const float *gnss_acq_plan_code_spectra_dev(const gnss_acq_plan *pl) { return pl ? reinterpret_cast<const float *>(pl->spectra_dev) : nullptr; }
+
+arm_status gnss_acquire_dev(const gnss_acq_plan *pl, const float *signal_dev, uint32_t n_scenes, uint32_t dop_begin, uint32_t dop_end,
+                            gnss_acq_result *all_dev, gnss_acq_result *best_dev, void *stream)
+{
+  if (!pl || !signal_dev || !all_dev) { set_error("gnss_acquire_dev: null argument"); return ARM_MATH_ARGUMENT_ERROR; }
+  if (dop_begin > dop_end || dop_end > (uint32_t)pl->n_dop) {
+    set_error("gnss_acquire_dev: Doppler range [%u, %u) outside the plan's %d bins", dop_begin, dop_end, pl->n_dop);
+    return ARM_MATH_ARGUMENT_ERROR;
+  }
+  if (n_scenes > 65535) { set_error("gnss_acquire_dev: at most 65535 scenes per call"); return ARM_MATH_ARGUMENT_ERROR; }
+  if (n_scenes == 0 || dop_begin == dop_end) return ARM_MATH_SUCCESS;
+  if (!plan_on_device(pl, "gnss_acquire_dev")) return ARM_MATH_ARGUMENT_ERROR;
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = GNSS_DISPATCH(launch_acquire, pl->logn, pl, reinterpret_cast<const float2 *>(signal_dev), n_scenes, (int)dop_begin,
+                               (int)dop_end, all_dev, s);
+  if (!hip_ok(e, "gnss_acquire_kernel launch")) return ARM_MATH_ARGUMENT_ERROR;
+  if (best_dev) {
+    const int rows = (int)n_scenes * pl->n_prn;
+    gnss_best_kernel<<<(rows + 255) / 256, 256, 0, s>>>(all_dev, best_dev, rows, pl->n_dop, (int)dop_begin, (int)dop_end);
+    if (!hip_ok(hipGetLastError(), "gnss_best_kernel launch")) return ARM_MATH_ARGUMENT_ERROR;
+  }
+  return ARM_MATH_SUCCESS;
+}
+
+arm_status gnss_acquire(gnss_acq_plan *pl, const float *signal, uint32_t n_scenes, gnss_acq_result *best, gnss_acq_result *all)
+{
+  if (!pl || !signal || !best) { set_error("gnss_acquire: null argument"); return ARM_MATH_ARGUMENT_ERROR; }
+  if (n_scenes == 0) return ARM_MATH_SUCCESS;
+  if (!plan_on_device(pl, "gnss_acquire")) return ARM_MATH_ARGUMENT_ERROR;
+  std::lock_guard<std::mutex> lk(pl->mu);
+  const size_t sig_elems = (size_t)n_scenes * pl->n_ms * pl->spm, rows = (size_t)n_scenes * pl->n_prn;
+  if (pl->stage_scenes < n_scenes) {
+    (void)hipFree(pl->sig_stage); (void)hipFree(pl->all_stage); (void)hipFree(pl->best_stage);
+    pl->sig_stage = nullptr; pl->all_stage = nullptr; pl->best_stage = nullptr; pl->stage_scenes = 0;
+    if (!hip_ok(hipMalloc((void **)&pl->sig_stage, sizeof(float2) * sig_elems), "hipMalloc(signal staging)") ||
+        !hip_ok(hipMalloc((void **)&pl->all_stage, sizeof(gnss_acq_result) * rows * pl->n_dop), "hipMalloc(cell staging)") ||
+        !hip_ok(hipMalloc((void **)&pl->best_stage, sizeof(gnss_acq_result) * rows), "hipMalloc(result staging)"))
+      return ARM_MATH_ARGUMENT_ERROR;
+    pl->stage_scenes = n_scenes;
+  }
+  if (!hip_ok(hipMemcpy(pl->sig_stage, signal, sizeof(float2) * sig_elems, hipMemcpyHostToDevice), "hipMemcpy(H2D)")) return ARM_MATH_ARGUMENT_ERROR;
+  arm_status st = gnss_acquire_dev(pl, reinterpret_cast<const float *>(pl->sig_stage), n_scenes, 0, (uint32_t)pl->n_dop, pl->all_stage,
+                                   pl->best_stage, nullptr);
+  if (st != ARM_MATH_SUCCESS) return st;
+  if (!hip_ok(hipMemcpy(best, pl->best_stage, sizeof(gnss_acq_result) * rows, hipMemcpyDeviceToHost), "hipMemcpy(D2H)")) return ARM_MATH_ARGUMENT_ERROR;
+  if (all && !hip_ok(hipMemcpy(all, pl->all_stage, sizeof(gnss_acq_result) * rows * pl->n_dop, hipMemcpyDeviceToHost), "hipMemcpy(D2H)"))
+    return ARM_MATH_ARGUMENT_ERROR;
+  return ARM_MATH_SUCCESS;
+}
+
+// ---- per-function probes (device pointers) ----
+static arm_status chips_for(int prn, int8_t **chips)
+{
+  if (prn < 1 || prn > 37) { set_error("PRN %d outside 1..37", prn); return ARM_MATH_ARGUMENT_ERROR; }
+  int32_t *p = nullptr;
+  if (!hip_ok(hipMalloc((void **)&p, sizeof(int32_t)), "hipMalloc") || !hip_ok(hipMalloc((void **)chips, kCodeLen), "hipMalloc")) return ARM_MATH_ARGUMENT_ERROR;
+  bool ok = hip_ok(hipMemcpy(p, &prn, sizeof(int32_t), hipMemcpyHostToDevice), "hipMemcpy");
+  if (ok) {
+    gnss_code_kernel<<<1, 256, 0, nullptr>>>(p, *chips);
+    ok = hip_ok(hipGetLastError(), "gnss_code_kernel") && hip_ok(hipStreamSynchronize(nullptr), "synchronise");
+  }
+  (void)hipFree(p);
+  if (!ok) { (void)hipFree(*chips); *chips = nullptr; return ARM_MATH_ARGUMENT_ERROR; }
+  return ARM_MATH_SUCCESS;
+}
+
+arm_status gnss_get_code_dev(int32_t num, int32_t samples_per_chip, int32_t prn, int32_t *out_dev)
+{
+  if (!out_dev || num < 0) { set_error("gnss_get_code_dev: bad argument"); return ARM_MATH_ARGUMENT_ERROR; }
+  if (samples_per_chip < 1) samples_per_chip = 1;  // gnss_codes.c:1010
+  if (num == 0) return ARM_MATH_SUCCESS;
+  int8_t *chips = nullptr;
+  arm_status st = chips_for(prn, &chips);
+  if (st != ARM_MATH_SUCCESS) return st;
+  const int total = num * samples_per_chip;
+  gnss_expand_code_kernel<<<(total + 255) / 256, 256, 0, nullptr>>>(chips, out_dev, total, samples_per_chip);
+  bool ok = hip_ok(hipGetLastError(), "gnss_expand_code_kernel") && hip_ok(hipStreamSynchronize(nullptr), "synchronise");
+  (void)hipFree(chips);
+  return ok ? ARM_MATH_SUCCESS : ARM_MATH_ARGUMENT_ERROR;
+}
+
+arm_status gnss_synth_gps_prn_dev(int32_t prn, float doppler, uint32_t size, float *replica_dev, int32_t samples_per_chip)
+{
+  if (!replica_dev || samples_per_chip < 1) { set_error("gnss_synth_gps_prn_dev: bad argument"); return ARM_MATH_ARGUMENT_ERROR; }
+  if (size == 0) return ARM_MATH_SUCCESS;
+  int8_t *chips = nullptr;
+  arm_status st = chips_for(prn, &chips);
+  if (st != ARM_MATH_SUCCESS) return st;
+  gnss_replica_kernel<<<(size + 255) / 256, 256, 0, nullptr>>>(chips, reinterpret_cast<float2 *>(replica_dev), (int)size, samples_per_chip,
+                                                               (double)doppler, 0.0);
+  bool ok = hip_ok(hipGetLastError(), "gnss_replica_kernel") && hip_ok(hipStreamSynchronize(nullptr), "synchronise");
+  (void)hipFree(chips);
+  return ok ? ARM_MATH_SUCCESS : ARM_MATH_ARGUMENT_ERROR;
+}
+
+arm_status gnss_find_top2_peaks_dev(const float *data_dev, int32_t is_complex, int32_t data_size, int32_t pk_sep, uint32_t batch,
+                                    gnss_top2 *peaks_dev, void *stream)
+{
+  if (!data_dev || !peaks_dev) { set_error("gnss_find_top2_peaks_dev: null argument"); return ARM_MATH_ARGUMENT_ERROR; }
+  if (data_size <= 0 || data_size > 16384 || pk_sep < 0) { set_error("gnss_find_top2_peaks_dev: data_size must be 1..16384"); return ARM_MATH_ARGUMENT_ERROR; }
+  if (batch == 0) return ARM_MATH_SUCCESS;
+  if (is_complex)
+    gnss_top2_kernel<true><<<batch, 256, 0, (hipStream_t)stream>>>(data_dev, data_size, pk_sep, peaks_dev);
+  else
+    gnss_top2_kernel<false><<<batch, 256, 0, (hipStream_t)stream>>>(data_dev, data_size, pk_sep, peaks_dev);
+  return hip_ok(hipGetLastError(), "gnss_top2_kernel launch") ? ARM_MATH_SUCCESS : ARM_MATH_ARGUMENT_ERROR;
+}
+
+}  // extern "C"

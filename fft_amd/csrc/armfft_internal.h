@@ -15,9 +15,13 @@ constexpr int kMinLargeLog = 15, kMaxLargeLog = 22;  // four-step through HBM
 void set_error(const char *fmt, ...);
 bool hip_ok(hipError_t e, const char *what);
 
+// per-device cached table exp(-2 pi i m / 2^logn), m < 2^logn (armfft_abi.cpp); nullptr + error on failure
+const float2 *dev_twiddle_f32(int logn);
+
 // ---- kernel launchers (no allocation, asynchronous on the stream) ----
 // f32 complex, in place; tw = device table of N entries exp(-2 pi i m / N)
-hipError_t launch_cfft_f32(int logn, float2 *data, const float2 *tw, uint32_t batch, bool inverse, bool scramble,
+// order: 0 natural, 1 arm_cfft_f32's radix-8 digit-scrambled order, 2 plain bit reversal (radix-2 API)
+hipError_t launch_cfft_f32(int logn, float2 *data, const float2 *tw, uint32_t batch, bool inverse, int order,
                            hipStream_t stream);
 // f32 real: n_real = 2^logn_real points; tw_c = table of the n_real/2-point complex transform,
 // tw_r = n_real/2 entries (sin, cos)(2 pi k / n_real)

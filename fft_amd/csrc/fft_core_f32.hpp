@@ -144,6 +144,20 @@ struct Preloaded {
   __device__ __forceinline__ float2 operator()(int, int) const { return make_float2(0.f, 0.f); }
 };
 
+// Calls f(slot, t, e) for the 16 first-pass inputs of thread tid: v[slot] = point e of sequence t.
+template <class PL, class F>
+__device__ __forceinline__ void for_each_first_pass_input(int tid, F f)
+{
+  constexpr int LR = PL::lr(0), R = 1 << LR, NB = 16 / R, LNR = PL::LOGN - LR;
+#pragma unroll
+  for (int q = 0; q < NB; q++) {
+    const int w = tid + q * PL::T;
+    const int t = w >> LNR, j = w & ((1 << LNR) - 1);
+#pragma unroll
+    for (int r = 0; r < R; r++) f(q * R + r, t, j + (r << LNR));
+  }
+}
+
 // ---- twiddle sources ----
 // The pass code asks for twiddle `slot` (= q*(R-1) + r-1) of pass P, whose table index is idx.
 // TwTable reads the device-generated table (L1/L2-resident, never HBM in steady state).

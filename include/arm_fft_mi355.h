@@ -170,6 +170,29 @@ arm_status arm_rfft_fast_batch_f32(const arm_rfft_fast_instance_f32 *S, float32_
 arm_status arm_rfft_fast_f32_dev(const arm_rfft_fast_instance_f32 *S, const float32_t *p_dev, float32_t *pOut_dev,
                                  uint32_t batch, uint8_t ifftFlag, void *stream);
 
+/* ---- f32 complex FFT, deprecated radix-2 API (what the fork's fft_c32 calls, CMSIS/CMSIS.cpp:218-234) ---- */
+/* Include/dsp/transform_functions.h:217-227 */
+typedef struct {
+  uint16_t fftLen;
+  uint8_t ifftFlag;
+  uint8_t bitReverseFlag;
+  const float32_t *pTwiddle;
+  const uint16_t *pBitRevTable;
+  uint16_t twidCoefModifier;
+  uint16_t bitRevFactor;
+  float32_t onebyfftLen;
+} arm_cfft_radix2_instance_f32;
+/* Include/dsp/transform_functions.h:231-235; body arm_cfft_radix2_init_f32.c:64-218 (16..16384 on the
+ * fork's shared 16384 tables).  Like the reference, the fields are written even when the length
+ * is refused with ARM_MATH_ARGUMENT_ERROR. */
+arm_status arm_cfft_radix2_init_f32(arm_cfft_radix2_instance_f32 *S, uint16_t fftLen, uint8_t ifftFlag, uint8_t bitReverseFlag);
+/* Include/dsp/transform_functions.h:238-240; body arm_cfft_radix2_f32.c:64-88 (butterflies :227-271,
+ * :392-463, arm_bitreversal_f32 arm_bitreversal.c:46-105).  Inverse scaled by onebyfftLen;
+ * bitReverseFlag 0 leaves plain bit-reversed order. */
+void arm_cfft_radix2_f32(const arm_cfft_radix2_instance_f32 *S, float32_t *pSrc);
+arm_status arm_cfft_radix2_batch_f32(const arm_cfft_radix2_instance_f32 *S, float32_t *pSrc, uint32_t batch);
+arm_status arm_cfft_radix2_f32_dev(const arm_cfft_radix2_instance_f32 *S, float32_t *pSrc_dev, uint32_t batch, void *stream);
+
 /* ---- large complex f32 FFT, 2^15 <= fftLen <= 2^22 (extension; BASELINE config 4) ----
  * No reference function runs these sizes: arm_cfft_f32 stops at 4096 (arm_cfft_f32.c:1263-1280) and
  * fftLen is a uint16_t in every reference instance (transform_functions.h:416-430), hence the
@@ -184,6 +207,66 @@ arm_status arm_cfft_u32_f32_dev(const arm_cfft_instance_u32_f32 *S, float32_t *p
                                 uint8_t ifftFlag, void *stream);
 /* host pointers; allocates its own device staging */
 arm_status arm_cfft_u32_batch_f32(const arm_cfft_instance_u32_f32 *S, float32_t *p1, uint32_t batch, uint8_t ifftFlag);
+
+/* ---- GNSS acquisition (BASELINE config 5) ----
+ * The reference searches one (PRN, Doppler) cell row at a time on the CPU (read_ors,
+ * CMSIS/CMSIS.cpp:706-737; coherent fold :1154-1169): replica = synth_gps_prn, three fft_c32,
+ * S*conj(R), find_top2_peaks_cplx, compute_snr_cplx, InterpolateCodePhase.  Here one fused kernel
+ * does every row of every scene; the tuple below is what the reference keeps per row. */
+typedef struct {
+  float32_t peak;            /* top2_pks.val1: largest correlation magnitude (IFFT scaled by 1/fft_len) */
+  float32_t second;          /* top2_pks.val2 (-1e10 when there is none, gnss_codes.c:1148) */
+  int32_t code_phase;        /* top2_pks.idx1, in samples */
+  int32_t second_phase;      /* top2_pks.idx2 (-1 when there is none) */
+  int32_t doppler_bin;       /* index into the plan's Doppler list */
+  int32_t prn;
+  float32_t snr_db;          /* compute_snr_cplx, gnss_codes.c:1110-1125 */
+  float32_t code_phase_interp; /* InterpolateCodePhase, gnss_codes.c:1096-1108 */
+} gnss_acq_result;
+
+/* Include/gnss_codes.h:42-47 (top2_pks) with 32-bit indices */
+typedef struct {
+  float32_t val1;
+  int32_t idx1;
+  float32_t val2;
+  int32_t idx2;
+} gnss_top2;
+
+typedef struct gnss_acq_plan gnss_acq_plan;
+
+/* Plan = geometry + PRN list + Doppler grid; generates the C/A codes (getCode, gnss_codes.c:969-1030)
+ * and their spectra on the current device.  fft_len in {1024..16384}; one millisecond is
+ * samples_per_ms samples (FS = 1.023e6 * samples_per_chip) zero-padded to fft_len (CMSIS.cpp:1154-1160);
+ * n_ms (<= 64) milliseconds are folded coherently; PRN 1..37 (<= 64 of them). */
+arm_status gnss_acq_plan_create(gnss_acq_plan **plan, uint32_t fft_len, uint32_t samples_per_ms, uint32_t n_ms,
+                                uint32_t samples_per_chip, const int32_t *prns, uint32_t n_prn, const float32_t *dopplers_hz,
+                                uint32_t n_dop);
+void gnss_acq_plan_destroy(gnss_acq_plan *plan);
+/* minimum distance between the two reported peaks, default 3 (the pk_sep of CMSIS.cpp:731) */
+arm_status gnss_acq_plan_set_peak_separation(gnss_acq_plan *plan, int32_t pk_sep);
+/* device pointer to the n_prn x fft_len complex code spectra (read-only; for tests) */
+const float32_t *gnss_acq_plan_code_spectra_dev(const gnss_acq_plan *plan);
+
+/* signal_dev: n_scenes x (n_ms * samples_per_ms) complex f32 (interleaved I/Q, the c32 of
+ * Include/cplx_types.h:9-12).  Searches Doppler bins [dop_begin, dop_end) of the plan (the unit a
+ * multi-GPU caller shards on) and writes all_dev[(scene * n_prn + p) * n_dop + d] for those bins;
+ * best_dev (optional) [scene * n_prn + p] = the bin with the largest peak among them, lowest bin
+ * on ties.  Asynchronous on `stream`, allocates nothing. */
+arm_status gnss_acquire_dev(const gnss_acq_plan *plan, const float32_t *signal_dev, uint32_t n_scenes, uint32_t dop_begin,
+                            uint32_t dop_end, gnss_acq_result *all_dev, gnss_acq_result *best_dev, void *stream);
+/* host pointers, all bins; `all` may be NULL */
+arm_status gnss_acquire(gnss_acq_plan *plan, const float32_t *signal, uint32_t n_scenes, gnss_acq_result *best,
+                        gnss_acq_result *all);
+
+/* Device-side counterparts of the reference's helpers, exported so each can be checked on its own:
+ * getCode (gnss_codes.c:969-1030): out_dev[num * samples_per_chip] ints, +1/-1;
+ * synth_gps_prn (gnss_codes.c:1066-1071, mix_prn :1032-1063): replica_dev[size] complex;
+ * find_top2_peaks_real / _cplx (gnss_codes.c:1144-1190): `batch` rows of data_size samples,
+ * same values AND indices as the sequential reference loop, ties included (data_size <= 16384). */
+arm_status gnss_get_code_dev(int32_t num, int32_t samples_per_chip, int32_t prn, int32_t *out_dev);
+arm_status gnss_synth_gps_prn_dev(int32_t prn, float32_t doppler, uint32_t size, float32_t *replica_dev, int32_t samples_per_chip);
+arm_status gnss_find_top2_peaks_dev(const float32_t *data_dev, int32_t is_complex, int32_t data_size, int32_t pk_sep, uint32_t batch,
+                                    gnss_top2 *peaks_dev, void *stream);
 
 /* ---- library services (no counterpart in the reference) ---- */
 /* Select the GPU used by the calling thread's host-pointer entry points and build nothing else;

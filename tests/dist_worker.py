@@ -1,0 +1,42 @@
+"""Worker of tests/test_dist_cpu.py: one rank of a world_size-N gloo job (CPU).  The per-rank
+acquisition results come from the oracle here (no GPU in this container); what is under test is
+the product's sharding + merge logic in fft_amd/dist.py, i.e. the N>1 path of bench.py and of a
+multi-GPU GNSS search."""
+import os
+import sys
+
+import numpy as np
+
+
+def run(rank, world, port, out_dir):
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import torch
+    import torch.distributed as dist
+
+    import helpers as H
+    from fft_amd import dist as D
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # --- GNSS: Doppler bins of one scene sharded over the ranks, one small collective ---
+        sig = H.make_gps_scene(n_ms=2, sigma=1.0)
+        prns = H.ALL_PRNS[:12]
+        d0, d1 = D.doppler_range(len(H.DOPPLER_GRID), rank, world)
+        if d1 > d0:
+            best, _ = H.oracle_acquire(sig, 2, 4092, 4096, 4, prns, H.DOPPLER_GRID[d0:d1], want_all=False)
+            best["doppler_bin"] += d0                      # local -> global bin index
+            mine = torch.from_numpy(best.view(np.int32).reshape(len(prns), 8).copy())
+        else:
+            mine = D.empty_best(len(prns), prns)
+        merged = D.merge_best(mine).numpy()
+        np.save(os.path.join(out_dir, "merged_%d.npy" % rank), merged)
+        # --- batched transforms: contiguous slices, no collective; only the timing reduction of bench.py ---
+        b0, b1 = D.batch_slice(1000, rank, world)
+        t = torch.tensor([float(b1 - b0), 1.0 + rank], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        np.save(os.path.join(out_dir, "slice_%d.npy" % rank), np.array([b0, b1, t[0].item(), t[1].item()]))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()

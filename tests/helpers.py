@@ -141,3 +141,55 @@ def rel_l2(test_v, ref_v):
 
 def rng(seed):
     return np.random.Generator(np.random.Philox(seed))
+
+
+# ---- synthetic GPS L1 C/A scenes (SURVEY 8(d) config 5) ----
+GPS_SCENE = dict(prns=[3, 7, 11, 19, 22, 30], phases=[100, 1033, 2047, 3000, 3555, 4000],
+                 dopplers=[-4250.0, -1500.0, 0.0, 750.0, 2250.0, 4750.0])
+DOPPLER_GRID = np.array([-5000.0 + 250.0 * k for k in range(41)], np.float32)
+ALL_PRNS = np.arange(1, 33, dtype=np.int32)
+
+
+def ca_code(prn, spc=4, num=1023):
+    """+1/-1 samples of one C/A code period from the oracle's getCode restatement."""
+    out = np.zeros(num * spc, np.int32)
+    oracle().orc_get_code(num, spc, prn, ptr(out, c_i32))
+    return out
+
+
+def make_gps_scene(seed=0x5EED0006, n_ms=10, spc=4, sigma=2.0, offset_hz=0.0, svs=None, amp=1.0):
+    """Complex f32 samples, n_ms * 1023 * spc of them: sum of code(prn) delayed by `phase` samples
+    with carrier e^{+j 2 pi f n / FS}, plus white Gaussian noise of std sigma per component."""
+    svs = svs or GPS_SCENE
+    spm = 1023 * spc
+    n = np.arange(n_ms * spm)
+    fs = 1.023e6 * spc
+    x = np.zeros(n.size, np.complex128)
+    for prn, ph, fd in zip(svs["prns"], svs["phases"], svs["dopplers"]):
+        c = ca_code(prn, spc).astype(np.float64)
+        x += amp * c[(n - ph) % spm] * np.exp(2j * np.pi * (fd + offset_hz) * n / fs)
+    g = rng(seed)
+    x += sigma * (g.standard_normal(n.size) + 1j * g.standard_normal(n.size))
+    out = np.empty((n.size, 2), np.float32)
+    out[:, 0] = x.real
+    out[:, 1] = x.imag
+    return out
+
+
+def oracle_acquire(signal, n_ms, spm, fft_len, spc, prns, dopplers, want_all=True):
+    """orc_acquire_fused -> (best[n_prn], all[n_prn][n_dop]) as numpy structured arrays."""
+    prns = np.ascontiguousarray(prns, np.int32)
+    dopplers = np.ascontiguousarray(dopplers, np.float32)
+    best = np.zeros(len(prns), ACQ_DTYPE)
+    allc = np.zeros((len(prns), len(dopplers)), ACQ_DTYPE)
+    sig = np.ascontiguousarray(signal, np.float32)
+    rc = oracle().orc_acquire_fused(sig.ctypes.data_as(ctypes.c_void_p), n_ms, spm, fft_len, spc, ptr(prns, c_i32), len(prns),
+                                    ptr(dopplers, c_f), len(dopplers), best.ctypes.data_as(ctypes.c_void_p),
+                                    allc.ctypes.data_as(ctypes.c_void_p) if want_all else None)
+    assert rc == 0
+    return best, allc
+
+
+ACQ_DTYPE = np.dtype([("peak", np.float32), ("second", np.float32), ("code_phase", np.int32), ("second_phase", np.int32),
+                      ("doppler_bin", np.int32), ("prn", np.int32), ("snr_db", np.float32), ("code_phase_interp", np.float32)])
+TOP2_DTYPE = np.dtype([("val1", np.float32), ("idx1", np.int32), ("val2", np.float32), ("idx2", np.int32)])

@@ -105,6 +105,41 @@ def test_rfft_init():
     assert lib.arm_rfft_fast_init_f32(None, 64) == fft_amd.ARM_MATH_ARGUMENT_ERROR   # arm_rfft_fast_init_f32.c:87
 
 
+def test_radix2_init_mirrors_reference_fields():
+    """arm_cfft_radix2_init_f32.c:64-218: modifiers 16384/N, table pointer offset modifier-1, fields
+    written even when the length is refused."""
+    R2 = fft_amd.arm_cfft_radix2_instance_f32
+    assert ctypes.sizeof(R2) == 32 and R2.pTwiddle.offset == 8 and R2.pBitRevTable.offset == 16 and R2.onebyfftLen.offset == 28
+    base = None
+    for n in (16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384):
+        S = R2()
+        assert lib.arm_cfft_radix2_init_f32(ctypes.byref(S), n, 1, 0) == 0
+        mod = 16384 // n
+        assert (S.fftLen, S.ifftFlag, S.bitReverseFlag, S.twidCoefModifier, S.bitRevFactor) == (n, 1, 0, mod, mod)
+        assert S.onebyfftLen == np.float32(1.0 / n)
+        addr = ctypes.cast(S.pBitRevTable, ctypes.c_void_p).value - 2 * (mod - 1)
+        base = base or addr
+        assert addr == base
+    tab = np.ctypeslib.as_array(ctypes.cast(base, ctypes.POINTER(ctypes.c_uint16)), shape=(4096,))
+    assert tab[0] == 4096 and tab[1] == 2048 and tab[2] == 6144          # 13-bit reversals of 1, 2, 3
+    tw = np.ctypeslib.as_array(S.pTwiddle, shape=(2 * 16384,))
+    want = np.zeros(2 * 16384, np.float32)
+    H.oracle().orc_twiddle_f32(16384, H.ptr(want, H.c_f))
+    assert np.array_equal(tw.view(np.uint32), want.view(np.uint32))
+    S = R2()
+    assert lib.arm_cfft_radix2_init_f32(ctypes.byref(S), 48, 1, 1) == fft_amd.ARM_MATH_ARGUMENT_ERROR
+    assert S.fftLen == 48 and S.ifftFlag == 1 and S.bitReverseFlag == 1 and bool(S.pTwiddle)
+
+
+def test_u32_init():
+    U = fft_amd.arm_cfft_instance_u32_f32()
+    for l in range(4, 23):
+        assert lib.arm_cfft_init_u32_f32(ctypes.byref(U), 1 << l) == 0 and U.fftLen == 1 << l
+    for bad in (0, 1, 8, 48, 1 << 23, (1 << 22) + 2):
+        assert lib.arm_cfft_init_u32_f32(ctypes.byref(U), bad) == fft_amd.ARM_MATH_ARGUMENT_ERROR
+    assert U.fftLen == 1 << 22
+
+
 def test_extension_sizes_are_accepted():
     S = fft_amd.arm_cfft_instance_f32()
     for n in (8192, 16384):

@@ -1,0 +1,272 @@
+"""GNSS acquisition on the GPU (rows a10-a16, BASELINE config 5), through the C ABI, against the CPU
+oracle (oracle/gnss_oracle.c) on the same synthetic scenes.  The reference has no golden vectors
+for this path (parity unpinned by the reference); bars: integer outputs (chips, peak indices,
+Doppler bins) identical to the oracle, float outputs within the tolerance written at each check."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import helpers as H
+from helpers import c_f, c_i32, ptr
+
+pytestmark = pytest.mark.gpu
+
+
+def _lib():
+    import fft_amd
+    return fft_amd, fft_amd.lib
+
+
+def _dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+class Plan:
+    def __init__(self, fft_len, spm, n_ms, spc, prns, dops):
+        fa, lib = _lib()
+        self.p = ctypes.c_void_p()
+        self.prns = np.ascontiguousarray(prns, np.int32)
+        self.dops = np.ascontiguousarray(dops, np.float32)
+        self.geo = (fft_len, spm, n_ms, spc)
+        st = lib.gnss_acq_plan_create(ctypes.byref(self.p), fft_len, spm, n_ms, spc, self.prns.ctypes.data_as(ctypes.c_void_p),
+                                      len(self.prns), self.dops.ctypes.data_as(ctypes.c_void_p), len(self.dops))
+        assert st == 0, fa.last_error()
+
+    def acquire_dev(self, sig, d0=0, d1=None, want_best=True):
+        import torch
+        import gpu_util as G
+        fa, lib = _lib()
+        fft_len, spm, n_ms, spc = self.geo
+        sig = np.ascontiguousarray(sig, np.float32).reshape(-1, n_ms * spm, 2)
+        ns, npn, nd = sig.shape[0], len(self.prns), len(self.dops)
+        d1 = nd if d1 is None else d1
+        t = _dev(sig)
+        allc = torch.zeros((ns, npn, nd, 8), dtype=torch.int32, device="cuda")
+        best = torch.zeros((ns, npn, 8), dtype=torch.int32, device="cuda")
+        G.check(lib.gnss_acquire_dev(self.p, ctypes.c_void_p(t.data_ptr()), ns, d0, d1, ctypes.c_void_p(allc.data_ptr()),
+                                     ctypes.c_void_p(best.data_ptr()) if want_best else None, G.stream_ptr()))
+        torch.cuda.synchronize()
+        return (best.cpu().numpy().view(H.ACQ_DTYPE).reshape(ns, npn), allc.cpu().numpy().view(H.ACQ_DTYPE).reshape(ns, npn, nd))
+
+    def close(self):
+        _lib()[1].gnss_acq_plan_destroy(self.p)
+
+
+def _same_cells(got, want, where=""):
+    """integer fields identical; peak/second 1e-4 relative; SNR 2e-3 dB; interpolated phase 2e-3 samples"""
+    for f in ("code_phase", "second_phase", "doppler_bin", "prn"):
+        assert np.array_equal(got[f], want[f]), "%s differs %s: %s" % (f, where, np.argwhere(got[f] != want[f])[:5])
+    assert np.allclose(got["peak"], want["peak"], rtol=1e-4, atol=0)
+    assert np.allclose(got["second"], want["second"], rtol=1e-4, atol=0)
+    assert np.abs(got["snr_db"] - want["snr_db"]).max() <= 2e-3
+    assert np.abs(got["code_phase_interp"] - want["code_phase_interp"]).max() <= 2e-3
+
+
+# ------------------------------------------------------------------ a10: getCode
+@pytest.mark.parametrize("spc,num", [(1, 1023), (4, 1023), (2, 1030), (16, 1023)])
+def test_get_code_dev_identical_to_oracle(spc, num):
+    import torch
+    fa, lib = _lib()
+    out = torch.zeros(num * spc, dtype=torch.int32, device="cuda")
+    for prn in range(1, 38):
+        assert lib.gnss_get_code_dev(num, spc, prn, ctypes.c_void_p(out.data_ptr())) == 0, fa.last_error()
+        want = np.zeros(num * spc, np.int32)
+        H.oracle().orc_get_code(num, spc, prn, ptr(want, c_i32))
+        assert np.array_equal(out.cpu().numpy(), want), prn
+    assert lib.gnss_get_code_dev(num, spc, 38, ctypes.c_void_p(out.data_ptr())) == fa.ARM_MATH_ARGUMENT_ERROR
+    assert lib.gnss_get_code_dev(num, spc, 0, ctypes.c_void_p(out.data_ptr())) == fa.ARM_MATH_ARGUMENT_ERROR
+
+
+# ------------------------------------------------------------------ a11: synth_gps_prn / mix_prn
+@pytest.mark.parametrize("prn,dop,size,spc", [(1, 1000.0, 4092, 4), (17, -4750.0, 4096, 4), (32, 2250.0, 16368, 16), (5, 0.0, 2046, 2)])
+def test_synth_gps_prn_dev_vs_oracle(prn, dop, size, spc):
+    import torch
+    fa, lib = _lib()
+    out = torch.zeros((size, 2), dtype=torch.float32, device="cuda")
+    assert lib.gnss_synth_gps_prn_dev(prn, dop, size, ctypes.c_void_p(out.data_ptr()), spc) == 0, fa.last_error()
+    want = np.zeros((size, 2), np.float32)
+    H.oracle().orc_synth_gps_prn(prn, dop, size, want.ctypes.data_as(ctypes.c_void_p), spc)
+    # the oracle (like mix_prn, gnss_codes.c:1032-1063) steps a double phasor recursively; the GPU evaluates
+    # the phase directly: both are within a few 1e-8 of the exact value, the outputs within 1 f32 ulp of 1.0
+    assert np.abs(out.cpu().numpy() - want).max() <= 1.2e-7
+
+
+# ------------------------------------------------------------------ a14: find_top2_peaks
+def _oracle_top2(rows, sep, cplx):
+    out = np.zeros(rows.shape[0], H.TOP2_DTYPE)
+    for i, r in enumerate(rows):
+        pk = H.OrcTop2()
+        r = np.ascontiguousarray(r)
+        if cplx:
+            assert H.oracle().orc_find_top2_peaks_cplx(r.ctypes.data_as(ctypes.c_void_p), r.shape[0], sep, ctypes.byref(pk)) == 0
+        else:
+            assert H.oracle().orc_find_top2_peaks_real(ptr(r, c_f), r.shape[0], sep, ctypes.byref(pk)) == 0
+        out[i] = (pk.val1, pk.idx1, pk.val2, pk.idx2)
+    return out
+
+
+def _gpu_top2(rows, sep, cplx):
+    import torch
+    import gpu_util as G
+    fa, lib = _lib()
+    t = _dev(rows)
+    out = torch.zeros((rows.shape[0], 4), dtype=torch.int32, device="cuda")
+    G.check(lib.gnss_find_top2_peaks_dev(ctypes.c_void_p(t.data_ptr()), int(cplx), rows.shape[1], sep, rows.shape[0],
+                                         ctypes.c_void_p(out.data_ptr()), G.stream_ptr()))
+    torch.cuda.synchronize()
+    return out.cpu().numpy().view(H.TOP2_DTYPE).reshape(-1)
+
+
+@pytest.mark.parametrize("sep", [0, 3, 50])
+@pytest.mark.parametrize("n", [1, 2, 5, 63, 64, 65, 1000, 4095, 4096, 16384])
+def test_top2_real_exact_including_ties(n, sep):
+    """Values AND indices of the sequential reference loop, on inputs built to hit its corner cases:
+    few distinct levels (ties everywhere), plateaus, monotone ramps, negatives."""
+    g = H.rng(5000 + n + sep)
+    rows = [
+        g.integers(0, 4, n).astype(np.float32),                  # heavy ties
+        g.integers(0, 50, n).astype(np.float32),
+        g.standard_normal(n).astype(np.float32),                 # negatives
+        np.arange(n, dtype=np.float32),                          # every sample a record
+        np.arange(n, dtype=np.float32)[::-1].copy(),             # first sample is the only record
+        np.full(n, 2.5, np.float32),                             # one plateau
+        (np.arange(n) % 7 == 0).astype(np.float32) * 3 + g.integers(0, 2, n).astype(np.float32),
+        np.abs(g.standard_normal(n)).astype(np.float32),
+    ]
+    rows = np.stack(rows)
+    got, want = _gpu_top2(rows, sep, False), _oracle_top2(rows, sep, False)
+    for f in ("idx1", "idx2", "val1", "val2"):
+        assert np.array_equal(got[f], want[f]), (f, got, want)
+
+
+@pytest.mark.parametrize("n", [7, 4096, 10000])
+def test_top2_cplx_exact(n):
+    g = H.rng(5100 + n)
+    rows = np.stack([g.standard_normal((n, 2)).astype(np.float32),
+                     g.integers(-3, 4, (n, 2)).astype(np.float32),        # |.| ties: 3-4-5 triangles and friends
+                     np.zeros((n, 2), np.float32)])
+    got, want = _gpu_top2(rows, 3, True), _oracle_top2(rows, 3, True)
+    for f in ("idx1", "idx2"):
+        assert np.array_equal(got[f], want[f]), (f, got, want)
+    assert np.allclose(got["val1"], want["val1"], rtol=2e-7) and np.allclose(got["val2"], want["val2"], rtol=2e-7)
+
+
+# ------------------------------------------------------------------ code spectra (a10 + a11 at zero Doppler + a13)
+def test_code_spectra_vs_oracle_fft():
+    import torch
+    fa, lib = _lib()
+    pl = Plan(4096, 4092, 1, 4, H.ALL_PRNS, H.DOPPLER_GRID[:1])
+    addr = lib.gnss_acq_plan_code_spectra_dev(pl.p)
+
+    class _Wrap:  # the library's device buffer seen by torch (no copy made by us, no second HIP runtime)
+        __cuda_array_interface__ = {"shape": (32, 4096, 2), "typestr": "<f4", "data": (addr, False), "version": 2}
+
+    got = torch.as_tensor(_Wrap(), device="cuda").cpu().numpy()
+    for prn in (1, 13, 32):
+        x = np.zeros((4096, 2), np.float64)
+        x[:4092, 0] = H.ca_code(prn, 4)
+        y = x.reshape(-1).copy()
+        assert H.oracle().orc_cfft_f64(ptr(y, H.c_d), 4096, 0) == 0
+        assert H.rel_l2(got[prn - 1].reshape(-1), y) <= 5e-7
+    pl.close()
+
+
+# ------------------------------------------------------------------ the acquisition itself
+@pytest.fixture(scope="module")
+def cfg5():
+    sig = H.make_gps_scene()
+    best, allc = H.oracle_acquire(sig, 10, 4092, 4096, 4, H.ALL_PRNS, H.DOPPLER_GRID)
+    return sig, best, allc
+
+
+def test_config5_scene_every_cell_vs_oracle(cfg5):
+    sig, want_best, want_all = cfg5
+    pl = Plan(4096, 4092, 10, 4, H.ALL_PRNS, H.DOPPLER_GRID)
+    best, allc = pl.acquire_dev(sig)
+    _same_cells(allc[0], want_all, "all cells")
+    _same_cells(best[0], want_best, "best per PRN")
+    # truth: the six SVs at their Doppler bins, code phase inside the flat top [phase, phase + 4]
+    for prn, ph, fd in zip(H.GPS_SCENE["prns"], H.GPS_SCENE["phases"], H.GPS_SCENE["dopplers"]):
+        b = best[0][prn - 1]
+        assert b["prn"] == prn and H.DOPPLER_GRID[b["doppler_bin"]] == fd and ph <= b["code_phase"] <= ph + 4
+    pl.close()
+
+
+def test_config5_host_api_and_doppler_sharding(cfg5):
+    """gnss_acquire (host pointers) == device entry point; two Doppler shards merged == one full call
+    (the multi-GPU partitioning of SURVEY 8(e), here on one device)."""
+    fa, lib = _lib()
+    sig, want_best, want_all = cfg5
+    pl = Plan(4096, 4092, 10, 4, H.ALL_PRNS, H.DOPPLER_GRID)
+    best = np.zeros(32, H.ACQ_DTYPE)
+    allc = np.zeros((32, 41), H.ACQ_DTYPE)
+    assert lib.gnss_acquire(pl.p, sig.ctypes.data_as(ctypes.c_void_p), 1, best.ctypes.data_as(ctypes.c_void_p),
+                            allc.ctypes.data_as(ctypes.c_void_p)) == 0, fa.last_error()
+    full_best, full_all = pl.acquire_dev(sig)
+    assert best.tobytes() == full_best[0].tobytes() and allc.tobytes() == full_all[0].tobytes()
+    b0, a0 = pl.acquire_dev(sig, 0, 20)
+    b1, a1 = pl.acquire_dev(sig, 20, 41)
+    assert a0[0][:, :20].tobytes() == full_all[0][:, :20].tobytes() and a1[0][:, 20:].tobytes() == full_all[0][:, 20:].tobytes()
+    merged = np.where(b1[0]["peak"] > b0[0]["peak"], b1[0], b0[0])          # lowest bin wins ties
+    assert merged.tobytes() == full_best[0].tobytes()
+    pl.close()
+
+
+def test_off_grid_scene_and_batch_of_scenes():
+    """Second scene of config 5 (+90 Hz off the grid: the 10 ms coherent sum keeps 11 % of the
+    amplitude) and a batch of independent scenes in one call."""
+    scenes = [H.make_gps_scene(offset_hz=90.0), H.make_gps_scene(seed=11), H.make_gps_scene(seed=12, sigma=0.5),
+              H.make_gps_scene(seed=13, svs=dict(prns=[1, 32], phases=[0, 4091], dopplers=[-5000.0, 5000.0]))]
+    pl = Plan(4096, 4092, 10, 4, H.ALL_PRNS, H.DOPPLER_GRID)
+    best, allc = pl.acquire_dev(np.stack(scenes))
+    for i, s in enumerate(scenes):
+        wb, wa = H.oracle_acquire(s, 10, 4092, 4096, 4, H.ALL_PRNS, H.DOPPLER_GRID)
+        _same_cells(allc[i], wa, "scene %d" % i)
+        _same_cells(best[i], wb, "scene %d best" % i)
+    pl.close()
+
+
+@pytest.mark.parametrize("fft_len,spc,n_ms,prns,nd", [(1024, 1, 4, [1, 2, 3], 5), (2048, 2, 3, [4, 9, 21, 37], 7), (8192, 8, 2, [6, 30], 4),
+                                                      (16384, 16, 2, [12, 25], 3), (4096, 4, 1, [8], 1), (4096, 4, 64, [2, 3], 2)])
+def test_other_geometries(fft_len, spc, n_ms, prns, nd):
+    spm = 1023 * spc
+    svs = dict(prns=prns[:1], phases=[spm // 3], dopplers=[250.0])
+    sig = H.make_gps_scene(seed=600 + fft_len + n_ms, n_ms=n_ms, spc=spc, sigma=1.0, svs=svs)
+    dops = np.array([250.0 * (k - nd // 2) for k in range(nd)], np.float32)
+    pl = Plan(fft_len, spm, n_ms, spc, prns, dops)
+    best, allc = pl.acquire_dev(sig)
+    wb, wa = H.oracle_acquire(sig, n_ms, spm, fft_len, spc, prns, dops)
+    _same_cells(allc[0], wa)
+    _same_cells(best[0], wb)
+    if nd >= 3:
+        assert best[0][0]["doppler_bin"] == nd // 2 + 1 and spm // 3 <= best[0][0]["code_phase"] <= spm // 3 + (fft_len - spm)
+    pl.close()
+
+
+def test_plan_argument_errors():
+    fa, lib = _lib()
+    p = ctypes.c_void_p()
+    prns = np.array([1, 2], np.int32)
+    dops = np.array([0.0], np.float32)
+    P, D = prns.ctypes.data_as(ctypes.c_void_p), dops.ctypes.data_as(ctypes.c_void_p)
+    bad = fa.ARM_MATH_ARGUMENT_ERROR
+    assert lib.gnss_acq_plan_create(ctypes.byref(p), 4000, 4000, 1, 4, P, 2, D, 1) == bad           # not a power of two
+    assert lib.gnss_acq_plan_create(ctypes.byref(p), 512, 500, 1, 1, P, 2, D, 1) == bad             # below 1024
+    assert lib.gnss_acq_plan_create(ctypes.byref(p), 4096, 4097, 1, 4, P, 2, D, 1) == bad           # a millisecond longer than the FFT
+    assert lib.gnss_acq_plan_create(ctypes.byref(p), 4096, 4092, 65, 4, P, 2, D, 1) == bad          # too many milliseconds
+    assert lib.gnss_acq_plan_create(ctypes.byref(p), 4096, 4092, 1, 4, P, 0, D, 1) == bad
+    prns[1] = 38
+    assert lib.gnss_acq_plan_create(ctypes.byref(p), 4096, 4092, 1, 4, P, 2, D, 1) == bad and "PRN" in fa.last_error()
+    assert not p.value
+    prns[1] = 2
+    assert lib.gnss_acq_plan_create(ctypes.byref(p), 4096, 4092, 1, 4, P, 2, D, 1) == 0
+    import torch
+    sig = torch.zeros((4092, 2), device="cuda")
+    out = torch.zeros((2, 1, 8), dtype=torch.int32, device="cuda")
+    assert lib.gnss_acquire_dev(p, ctypes.c_void_p(sig.data_ptr()), 1, 0, 2, ctypes.c_void_p(out.data_ptr()), None, None) == bad
+    assert lib.gnss_acquire_dev(p, None, 1, 0, 1, ctypes.c_void_p(out.data_ptr()), None, None) == bad
+    assert lib.gnss_acquire_dev(p, ctypes.c_void_p(sig.data_ptr()), 0, 0, 1, ctypes.c_void_p(out.data_ptr()), None, None) == 0
+    lib.gnss_acq_plan_destroy(p)
+    lib.gnss_acq_plan_destroy(None)

@@ -83,6 +83,30 @@ def test_cfft_f32_extension_sizes_vs_f64(n, ifft):
     assert H.rel_l2(got, want) <= F32_TOL
 
 
+@pytest.mark.parametrize("bitrev", [1, 0])
+@pytest.mark.parametrize("ifft", [0, 1])
+@pytest.mark.parametrize("n", CFFT_SIZES + EXT_SIZES)
+def test_cfft_radix2_f32_vs_oracle(n, ifft, bitrev):
+    """The deprecated radix-2 API (what fft_c32 calls, CMSIS/CMSIS.cpp:218-234) through the same kernels."""
+    import fft_amd
+    import torch
+    G = _gpu()
+    batch = 3
+    x = H.rng(1300 + n).uniform(-1, 1, (batch, 2 * n)).astype(np.float32)
+    want = x.copy()
+    for b in range(batch):
+        assert H.oracle().orc_cfft_radix2_f32(ptr(want[b], c_f), n, ifft, bitrev) == 0
+    S = fft_amd.arm_cfft_radix2_instance_f32()
+    G.check(fft_amd.lib.arm_cfft_radix2_init_f32(ctypes.byref(S), n, ifft, bitrev))
+    t = torch.from_numpy(x).cuda()
+    G.check(fft_amd.lib.arm_cfft_radix2_f32_dev(ctypes.byref(S), ctypes.c_void_p(t.data_ptr()), batch, G.stream_ptr()))
+    torch.cuda.synchronize()
+    assert H.rel_l2(t.cpu().numpy(), want) <= F32_TOL
+    y = x[0].copy()                                        # host-pointer drop-in
+    fft_amd.lib.arm_cfft_radix2_f32(ctypes.byref(S), y.ctypes.data_as(ctypes.c_void_p))
+    assert np.array_equal(y, t[0].cpu().numpy())
+
+
 def test_cfft_f32_full_batch_properties():
     """BASELINE config 2 size (65536 x 4096): size-independent checks on the whole batch plus the
     oracle on a 64-transform subset."""

@@ -1,0 +1,129 @@
+"""CPU checks of the GNSS part of the oracle (oracle/gnss_oracle.c).  The reference holds no golden
+vector for this path ("parity unpinned by the reference"): getCode is pinned by the public
+IS-GPS-200 first-10-chips table, the rest by analytic cases and by the agreement of the fused
+formulation (what the GPU implements) with the per-cell recipe of read_ors (CMSIS/CMSIS.cpp:706-737)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import helpers as H
+from helpers import c_f, c_i32, ptr
+
+# IS-GPS-200 Table 3-Ia, "first 10 chips octal" (logic levels; getCode maps logic 1 -> +1)
+ICD_FIRST10 = {1: 0o1440, 2: 0o1620, 3: 0o1710, 4: 0o1744, 5: 0o1133, 6: 0o1455, 7: 0o1131, 8: 0o1454, 9: 0o1626,
+               10: 0o1504, 11: 0o1642, 12: 0o1750, 13: 0o1764, 14: 0o1772, 15: 0o1775, 16: 0o1776, 17: 0o1156,
+               18: 0o1467, 19: 0o1633, 20: 0o1715, 21: 0o1746, 22: 0o1763, 23: 0o1063, 24: 0o1706, 25: 0o1743,
+               26: 0o1761, 27: 0o1770, 28: 0o1774, 29: 0o1127, 30: 0o1453, 31: 0o1625, 32: 0o1712}
+
+
+@pytest.mark.parametrize("prn", sorted(ICD_FIRST10))
+def test_get_code_matches_icd_first_10_chips(prn):
+    c = H.ca_code(prn, spc=1)
+    bits = (c[:10] > 0).astype(int)
+    assert int("".join(map(str, bits)), 2) == ICD_FIRST10[prn]
+    assert set(np.unique(c)) == {-1, 1} and c.sum() == 1            # balanced Gold code: 512 ones, 511 zeros
+
+
+def test_get_code_gold_correlation_and_hold():
+    a, b = H.ca_code(1, 1).astype(np.int64), H.ca_code(2, 1).astype(np.int64)
+    auto = np.array([np.dot(a, np.roll(a, k)) for k in range(1023)])
+    assert auto[0] == 1023 and set(np.unique(auto[1:])) <= {-1, 63, -65}
+    cross = np.array([np.dot(a, np.roll(b, k)) for k in range(1023)])
+    assert set(np.unique(cross)) <= {-1, 63, -65}
+    assert np.array_equal(H.ca_code(7, 4), np.repeat(H.ca_code(7, 1), 4))          # sample-and-hold
+    assert np.array_equal(H.ca_code(34, 1), H.ca_code(37, 1))                       # same taps {3,9}, gnss_codes.c:1004-1007
+    long = np.zeros(1030, np.int32)
+    H.oracle().orc_get_code(1030, 1, 5, ptr(long, c_i32))
+    assert np.array_equal(long[1023:], long[:7])                                    # period 1023
+
+
+def test_synth_gps_prn_phase_progression():
+    rep = np.zeros((4092, 2), np.float32)
+    H.oracle().orc_synth_gps_prn(1, 1000.0, 4092, rep.ctypes.data_as(ctypes.c_void_p), 4)
+    z = (rep[:, 0] + 1j * rep[:, 1]) * H.ca_code(1, 4)
+    want = np.exp(2j * np.pi * 1000.0 * np.arange(4092) / 4.092e6)
+    assert np.abs(z - want).max() < 2e-7
+    assert abs(z[1] - (0.999999 + 0.001535j)) < 1e-6                                # the value SURVEY 8(c) records
+
+
+def _top2(x, sep):
+    x = np.ascontiguousarray(x, np.float32)
+    pk = H.OrcTop2()
+    assert H.oracle().orc_find_top2_peaks_real(ptr(x, c_f), x.size, sep, ctypes.byref(pk)) == 0
+    return (pk.val1, pk.idx1, pk.val2, pk.idx2)
+
+
+def test_top2_sequential_semantics():
+    """gnss_codes.c:1144-1190: last index wins ties for the best; the runner-up must be > sep away
+    from whichever index was best when it was seen."""
+    assert _top2([1, 5, 2, 2, 2, 4, 0], 3) == (5.0, 1, 4.0, 5)
+    assert _top2([1, 5, 4.5, 2, 2, 4, 0], 3) == (5.0, 1, 4.0, 5)             # 4.5 too close to the best
+    assert _top2([3, 3, 3, 3, 3, 3], 3) == (3.0, 5, -1e10, -1)               # ties: every sample is a record, never > sep from the last
+    assert _top2([3, 0, 0, 0, 0, 3], 3) == (3.0, 5, 3.0, 0)                  # tie far away: old best handed down
+    assert _top2([7, 0, 0, 0, 0, 9], 3) == (9.0, 5, 7.0, 0)                  # old best handed down
+    assert _top2([7, 0, 9], 3) == (9.0, 2, -1e10, -1)                        # nothing far enough
+    assert _top2([4, 0, 0, 0, 0, 6, 0, 0, 0, 0, 5], 3)[2:] == (5.0, 10)      # later non-record beats the handed-down 4
+    assert _top2([2.0], 3) == (2.0, 0, -1e10, -1)
+
+
+def test_snr_and_interpolation_formulas():
+    y = np.zeros((64, 2), np.float32)
+    y[:, 0] = 2.0
+    y[10, 0] = 40.0
+    snr = H.oracle().orc_compute_snr_cplx(y.ctypes.data_as(ctypes.c_void_p), 64, 40.0, 10)
+    assert abs(snr - 10 * np.log10(40.0 / (2.0 * 59 / 59))) < 1e-12              # 5 samples around the peak excluded
+    f = H.oracle().orc_interpolate_code_phase
+    assert f(100, 1.0, 4.0, 1.0) == 100.0
+    assert abs(f(100, 1.0, 4.0, 2.0) - (100 + (0.5 * 1 / 3) / 3 * (2 * (0.5 * 1 / 3) + 2))) < 1e-12
+    assert abs(f(100, 2.0, 4.0, 1.0) - (100 + (-0.5 * 1 / 3) / 3 * (-2 * (-0.5 * 1 / 3) + 2))) < 1e-12
+
+
+def test_fused_form_agrees_with_read_ors_recipe():
+    """One millisecond, code filling the whole FFT length, Dopplers that are multiples of FS/N: the
+    fused form (wipe-off on the signal, precomputed code spectrum) and the per-cell recipe (carrier
+    on the replica, three FFTs) give the same correlation magnitudes and the same peaks.  (At other
+    Dopplers the replica's carrier is not periodic in N, so the recipe's CIRCULAR correlation sees a
+    phase step of 2 pi f N / FS at the wrap that the wipe-off form does not have; config 5 is
+    defined on the wipe-off form, rows a15/a16.)"""
+    n = 4096
+    f0 = 4.092e6 / 4096
+    svs = dict(prns=[5, 17], phases=[700, 3100], dopplers=[f0, -2 * f0])
+    idx = np.arange(n)
+    x = np.zeros(n, np.complex128)
+    for prn, ph, fd in zip(svs["prns"], svs["phases"], svs["dopplers"]):
+        c = H.ca_code(prn, 4, 1024).astype(np.float64)
+        x += c[(idx - ph) % n] * np.exp(2j * np.pi * fd * idx / 4.092e6)
+    g = H.rng(77)
+    x += 1.5 * (g.standard_normal(n) + 1j * g.standard_normal(n))
+    sig = np.stack([x.real, x.imag], 1).astype(np.float32)
+    dops = np.array([-2 * f0, 0.0, f0], np.float32)
+    prns = np.array([5, 9, 17], np.int32)
+    best, allc = H.oracle_acquire(sig, 1, n, n, 4, prns, dops)
+    for pi, prn in enumerate(prns):
+        for di, fd in enumerate(dops):
+            pk = H.OrcTop2()
+            assert H.oracle().orc_acquire_cell_reference(sig.ctypes.data_as(ctypes.c_void_p), n, int(prn), float(fd), 4,
+                                                         ctypes.byref(pk), None) == 0
+            cell = allc[pi, di]
+            assert abs(cell["peak"] - pk.val1) <= 2e-4 * pk.val1
+            if (prn, fd) in ((5, np.float32(f0)), (17, np.float32(-2 * f0))):
+                assert cell["code_phase"] == pk.idx1
+    assert best[0]["code_phase"] == 700 and best[0]["doppler_bin"] == 2
+    assert best[2]["code_phase"] == 3100 and best[2]["doppler_bin"] == 0
+    assert best[0]["peak"] / best[0]["second"] > 1.3 and best[2]["peak"] / best[2]["second"] > 1.3   # CMSIS.cpp:737 acceptance ratio
+    assert best[1]["peak"] < 0.3 * best[0]["peak"]
+
+
+def test_config5_scene_truth():
+    """The config-5 scene: every visible SV is found at its Doppler bin; the zero-padding of 4092
+    samples to 4096 (CMSIS.cpp:1154-1160) splits the peak between `phase` and `phase + 4` (4 samples per chip: the two triangles overlap)."""
+    sig = H.make_gps_scene()
+    best, _ = H.oracle_acquire(sig, 10, 4092, 4096, 4, H.ALL_PRNS, H.DOPPLER_GRID, want_all=False)
+    for prn, ph, fd in zip(H.GPS_SCENE["prns"], H.GPS_SCENE["phases"], H.GPS_SCENE["dopplers"]):
+        b = best[prn - 1]
+        assert b["prn"] == prn and H.DOPPLER_GRID[b["doppler_bin"]] == fd
+        assert ph <= b["code_phase"] <= ph + 4      # two triangles 4 samples apart: flat top between them
+        assert b["peak"] / b["second"] > 1.3 or ph <= b["second_phase"] <= ph + 8
+    quiet = [p for p in range(1, 33) if p not in H.GPS_SCENE["prns"]]
+    assert max(best[p - 1]["snr_db"] for p in quiet) < min(best[p - 1]["snr_db"] for p in H.GPS_SCENE["prns"])
