@@ -38,6 +38,8 @@ WORKLOADS = {
     "rfft_f32_16384x16384": dict(kind="rfft", n=16384, batch=16384, dtype="f32"),
     "cfft_f32_4194304x8": dict(kind="large", n=1 << 22, batch=8, dtype="f32"),   # BASELINE config 4, four-step
     "cfft_f32_4194304x64": dict(kind="large", n=1 << 22, batch=64, dtype="f32"),
+    # BASELINE config 5: GPS L1 C/A acquisition, 32 PRN x 41 Doppler x 4096 code phases, 10 ms coherent, 256 scenes
+    "gnss_acq_gps_l1_x256": dict(kind="gnss", n=4096, batch=256, dtype="f32"),
 }
 
 
@@ -62,6 +64,8 @@ def cpu_baseline(kind, n, seconds):
     orc_so = os.path.join(ROOT, "oracle", "liboracle.so")
     if kind == "large":
         return cpu_baseline_large(n, seconds)
+    if kind == "gnss":
+        return cpu_baseline_gnss(seconds)
     use_ref = os.path.exists(ref_so) and kind in ("f32", "q15", "q31") and n <= 4096
     use_ref = use_ref or (os.path.exists(ref_so) and kind == "rfft" and n <= 4096)
     if use_ref:
@@ -168,6 +172,35 @@ def cpu_baseline_large(n, seconds):
                       "%d transforms in %.0f s on one core" % (n, done, seconds)}
 
 
+def cpu_baseline_gnss(seconds):
+    """The fork's per-cell recipe (read_ors, CMSIS/CMSIS.cpp:706-737: replica synthesis, three radix-2
+    FFTs, spectrum product, top-2 peak search) restated in oracle/gnss_oracle.c, one core."""
+    import numpy as np
+    orc_so = os.path.join(ROOT, "oracle", "liboracle.so")
+    if not os.path.exists(orc_so):
+        return None
+    L = ctypes.CDLL(orc_so)
+
+    class Top2(ctypes.Structure):
+        _fields_ = [("val1", ctypes.c_float), ("idx1", ctypes.c_int), ("val2", ctypes.c_float), ("idx2", ctypes.c_int)]
+
+    L.orc_acquire_cell_reference.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int,
+                                             ctypes.POINTER(Top2), ctypes.c_void_p]
+    sig = np.random.default_rng(5).standard_normal((4096, 2)).astype(np.float32)
+    pk = Top2()
+    rows, busy, deadline = 0, 0.0, time.perf_counter() + seconds
+    while time.perf_counter() < deadline:
+        t0 = time.perf_counter()
+        for k in range(41):
+            L.orc_acquire_cell_reference(sig.ctypes.data_as(ctypes.c_void_p), 4096, 1 + rows // 41 % 32, -5000.0 + 250.0 * k, 4,
+                                         ctypes.byref(pk), None)
+        busy += time.perf_counter() - t0
+        rows += 41
+    return {"value": round(rows * 4096 / busy, 1), "unit": "cells/s", "cores": 1, "kind": "port",
+            "sample": "%d (PRN, Doppler) rows of 4096 code phases, ONE millisecond each (the reference's 10 ms fold costs it 9 more "
+                      "forward FFTs per row, not counted), %.0f s on one core, %.1f us per row" % (rows, seconds, 1e6 * busy / rows)}
+
+
 def main():
     args = parse()
     import numpy as np
@@ -220,6 +253,36 @@ def main():
         # algorithmic bytes per SURVEY 8(d): 16*N per transform; the four-step moves every point twice
         bytes_per_xform, flops_per_xform = 16 * n, 5.0 * n * np.log2(n)
         kernel_name = "fourstep_pass_kernel<11, 1|2, false> (two launches per step)"
+    elif kind == "gnss":
+        n_ms, spc, spm = 10, 4, 4092
+        prns = np.arange(1, 33, dtype=np.int32)
+        dops = np.array([-5000.0 + 250.0 * k for k in range(41)], np.float32)
+        plan = ctypes.c_void_p()
+        assert lib.gnss_acq_plan_create(ctypes.byref(plan), n, spm, n_ms, spc, prns.ctypes.data_as(ctypes.c_void_p), len(prns),
+                                        dops.ctypes.data_as(ctypes.c_void_p), len(dops)) == 0, fft_amd.last_error()
+        # synthetic scenes on the device: six C/A signals (codes from the library's own getCode kernel)
+        # at fixed delays/Dopplers + white Gaussian noise, sigma 2.0 per component, a new draw per scene
+        nn = n_ms * spm
+        tt = torch.arange(nn, device="cuda", dtype=torch.float64)
+        clean = torch.zeros((nn, 2), device="cuda", dtype=torch.float64)
+        code = torch.zeros(spm, dtype=torch.int32, device="cuda")
+        for prn, ph, fd in zip([3, 7, 11, 19, 22, 30], [100, 1033, 2047, 3000, 3555, 4000], [-4250.0, -1500.0, 0.0, 750.0, 2250.0, 4750.0]):
+            assert lib.gnss_get_code_dev(1023, spc, prn, ctypes.c_void_p(code.data_ptr())) == 0, fft_amd.last_error()
+            c = code.double()[(torch.arange(nn, device="cuda") - ph) % spm]
+            arg = 2 * np.pi * fd * tt / (1.023e6 * spc)
+            clean[:, 0] += c * torch.cos(arg)
+            clean[:, 1] += c * torch.sin(arg)
+        data = (clean.float()[None] + 2.0 * torch.randn((batch, nn, 2), device="cuda", generator=gen)).contiguous()
+        cells = torch.zeros((batch, len(prns), len(dops), 8), dtype=torch.int32, device="cuda")
+        best = torch.zeros((batch, len(prns), 8), dtype=torch.int32, device="cuda")
+        step = lambda: lib.gnss_acquire_dev(plan, ctypes.c_void_p(data.data_ptr()), batch, 0, len(dops), ctypes.c_void_p(cells.data_ptr()),
+                                            ctypes.c_void_p(best.data_ptr()), stream)
+        rescale, chunk = None, 1 << 30
+        rows_per_scene = len(prns) * len(dops)
+        # "transform" = one scene; flops at 5NlogN per FFT: one forward per Doppler bin + one inverse per (PRN, bin)
+        flops_per_xform = (len(dops) + rows_per_scene) * 5.0 * n * np.log2(n)
+        bytes_per_xform = nn * 8 + rows_per_scene * 32                      # compulsory HBM bytes: signal in, tuples out
+        kernel_name = "gnss_acquire_kernel<12>"
     elif kind in ("q15", "q31"):
         I = fft_amd.arm_cfft_instance_q15 if kind == "q15" else fft_amd.arm_cfft_instance_q31
         S = I()
@@ -296,11 +359,16 @@ def main():
                 traffic = json.load(open(tp)).get(args.workload)
             except Exception:
                 traffic = None
+        if kind == "gnss":
+            metric, value, unit = "GNSS acquisition cells/s (PRN x Doppler bin x code phase)", round(batch * K * world * 32 * 41 * 4096 / elapsed, 1), "cells/s"
+        elif args.workload == "cfft_f32_4096x65536":
+            metric, value, unit = "batched cfft_f32 4096-pt GFLOP/s (5NlogN) + % HBM roofline; GNSS acq cells/s", round(gflops, 2), "GFLOP/s"
+        else:
+            metric, value, unit = args.workload + " GFLOP/s", round(gflops, 2), "GFLOP/s"
         line = {
-            "metric": "batched cfft_f32 4096-pt GFLOP/s (5NlogN) + % HBM roofline; GNSS acq cells/s"
-                      if args.workload == "cfft_f32_4096x65536" else args.workload + " GFLOP/s",
-            "value": round(gflops, 2),
-            "unit": "GFLOP/s",
+            "metric": metric,
+            "value": value,
+            "unit": unit,
             "n_gpus": world,
             "steps": K,
             "warmup": W,
@@ -318,6 +386,15 @@ def main():
                          "algorithmic_bytes_per_launch": batch * bytes_per_xform,
                          "avg_launch_ms": round(1e3 * launch_s, 4)},
         }
+        if kind == "gnss":
+            # not HBM-bound: priced against the fp32 vector peak, 157.3 TFLOP/s
+            tf = batch * flops_per_xform / launch_s / 1e12
+            line["roofline"] = {"bound": "fp32-valu (LDS-resident FFTs; HBM traffic is only signal in + tuples out)",
+                                "achieved": round(tf, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(tf / 157.3, 4),
+                                "traffic": traffic, "kernel": kernel_name, "algorithmic_flops_per_launch": batch * flops_per_xform,
+                                "compulsory_hbm_bytes_per_launch": batch * bytes_per_xform, "avg_launch_ms": round(1e3 * launch_s, 4)}
+            line["config"].update({"prns": 32, "doppler_bins": 41, "coherent_ms": 10, "scenes_per_gpu": batch,
+                                   "sharding": "scenes per GPU, no collective"})
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(kind, n, args.cpu_seconds)
         print(json.dumps(line), flush=True)
