@@ -318,7 +318,7 @@ static const float2 *dev_tw_lo(int logn)
   std::lock_guard<std::mutex> lk(g_dev_mu);
   float2 *&p = g_dev[dev].tw_lo[logn];
   if (!p) {
-    if (!hip_ok(hipMalloc((void **)&p, sizeof(float2) * 2048), "hipMalloc(lo twiddle)")) { p = nullptr; return nullptr; }
+    if (!hip_ok(hipMalloc((void **)&p, sizeof(float2) * 1024), "hipMalloc(lo twiddle)")) { p = nullptr; return nullptr; }
     if (!hip_ok(launch_gen_twiddle_lo(p, logn, nullptr), "lo twiddle generation") || !hip_ok(hipStreamSynchronize(nullptr), "sync")) {
       (void)hipFree(p);
       p = nullptr;
@@ -584,7 +584,7 @@ arm_status arm_cfft_u32_f32_dev(const arm_cfft_instance_u32_f32 *S, float32_t *p
   if (l < kMinLargeLog || l > kMaxLargeLog) { set_error("arm_cfft_u32_f32_dev: unsupported fftLen %u", S->fftLen); return ARM_MATH_ARGUMENT_ERROR; }
   if (!work || work == p) { set_error("arm_cfft_u32_f32_dev: a separate workspace of batch*fftLen*8 bytes is required"); return ARM_MATH_ARGUMENT_ERROR; }
   const int l2 = l / 2, l1 = l - l2;
-  const float2 *tw1 = dev_tw_f32(l1), *tw2 = dev_tw_f32(l2), *lo = dev_tw_lo(l), *hi = dev_tw_f32(l - 11);
+  const float2 *tw1 = dev_tw_f32(l1), *tw2 = dev_tw_f32(l2), *lo = dev_tw_lo(l), *hi = dev_tw_f32(l - 10);
   if (!tw1 || !tw2 || !lo || !hi) return ARM_MATH_ARGUMENT_ERROR;
   hipError_t e = launch_cfft_large_f32(l, reinterpret_cast<float2 *>(p), reinterpret_cast<float2 *>(work), tw1, tw2, lo, hi, batch,
                                        ifft != 0, (hipStream_t)stream);

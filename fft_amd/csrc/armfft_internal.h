@@ -36,7 +36,7 @@ hipError_t launch_cfft_q31(int logn, int32_t *data, const int32_t *tw, uint32_t 
 // large complex f32 (2^15..2^22), four-step: data -> work -> data
 hipError_t launch_cfft_large_f32(int logn, float2 *data, float2 *work, const float2 *tw1, const float2 *tw2,
                                  const float2 *tw_lo, const float2 *tw_hi, uint32_t batch, bool inverse, hipStream_t stream);
-hipError_t launch_gen_twiddle_lo(float2 *tw, int logn, hipStream_t stream);  // exp(-2 pi i m / 2^logn), m < 2048
+hipError_t launch_gen_twiddle_lo(float2 *tw, int logn, hipStream_t stream);  // exp(-2 pi i m / 2^logn), m < 1024
 
 // on-device table generation
 hipError_t launch_gen_twiddle_f32(float2 *tw, uint32_t n, hipStream_t stream);        // exp(-2 pi i m/n), m < n

@@ -21,57 +21,100 @@
 
 namespace armfft {
 
-constexpr int kLoLog = 11;  // W_N^m = lo[m & 2047] * hi[m >> 11]: two correctly rounded tables
+constexpr int kLoLog = 10;  // W_N^m = lo[m & 1023] * hi[m >> 10]: two correctly rounded tables; lo (8 KiB) lives in LDS
 
 // MODE 1: tile in -> FFT -> * W_N^(seq * k) -> rows out.   MODE 2: tile in -> FFT -> tile out.
+// Persistent workgroups, (a) XCD-aware: workgroups are dispatched round-robin over the 8 XCDs
+// (XCD = blockIdx % 8), each XCD has its own L2, and neighbouring column tiles share 128-byte lines
+// when C*8 = 64 (measured: 2x over-fetch when they are read at unrelated times/places).  So the
+// workgroups b and b + 8 -- same XCD, running side by side -- always work on the two tiles of one
+// pair (2q, 2q+1) in the same iteration: the second reader and the second writer of a line find it
+// in that XCD's L2.  (b) The next tile's 16 loads per thread are in flight (in registers) while
+// the current tile is transformed: with 145 KiB of LDS only one workgroup fits a CU, so without
+// this the memory system idles during every FFT.
 template <int LOGA, int MODE, bool INV>
 __global__ __launch_bounds__(1024, 4) void fourstep_pass_kernel(const float2 *__restrict__ in, float2 *__restrict__ out,
                                                                 const float2 *__restrict__ tw,      // 2^LOGA-point table
-                                                                const float2 *__restrict__ tw_lo,   // exp(-2 pi i m / N), m < 2048
-                                                                const float2 *__restrict__ tw_hi,   // exp(-2 pi i m / (N/2048))
+                                                                const float2 *__restrict__ tw_lo,   // exp(-2 pi i m / N), m < 1024
+                                                                const float2 *__restrict__ tw_hi,   // exp(-2 pi i m / (N/1024))
                                                                 int log_other,                      // log2 of the other factor
-                                                                uint32_t tiles_per_xform, float scale)
+                                                                uint32_t tiles_per_xform, uint32_t n_items, int paired, float scale)
 {
   using PL = Plan<LOGA, 1024>;
   constexpr int A = PL::N, C = PL::TPB;
+  static_assert(A * C == 16 * 1024, "16 points per thread");
   extern __shared__ __attribute__((aligned(16))) float2 lds[];
-  const int tid = threadIdx.x;
-  const uint32_t tile = blockIdx.x % tiles_per_xform, xf = blockIdx.x / tiles_per_xform;
   const uint32_t other = 1u << log_other;  // row length of the matrix the tile is cut from
-  const uint32_t c0 = tile * C;
   const size_t nfull = (size_t)A << log_other;
-  const float2 *__restrict__ src = in + (size_t)xf * nfull;
-  float2 *__restrict__ dst = out + (size_t)xf * nfull;
-
-  // ---- gather the A x C tile: element (row a, column c0 + c) -> sequence c, point a ----
-#pragma unroll 4
-  for (int v = tid; v < A * C; v += 1024) {
-    const int c = v % C, a = v / C;
-    float2 x = src[(size_t)a * other + c0 + c];
-    if (MODE == 1 && INV) x.y = -x.y;  // inverse = conj(FFT(conj x)) / N
-    lds[PL::idx(c, a)] = x;
-  }
-  __syncthreads();
-
-  auto ld = [&](int t, int e) -> float2 { return lds[PL::idx(t, e)]; };
-  if (MODE == 1) {
-    auto st = [&](int t, int k, float2 v) {
-      const uint32_t m = (c0 + (uint32_t)t) * (uint32_t)k;  // < N
-      const float2 w = cmul(tw_lo[m & ((1u << kLoLog) - 1)], tw_hi[m >> kLoLog]);
-      dst[(size_t)(c0 + t) * A + k] = cmul(v, w);
-    };
-    fft_block<PL, true, false>(lds, tw, tid, ld, st);
+  // item of iteration i for this workgroup (>= n_items: done)
+  uint32_t first, stride;
+  if (paired) {
+    const uint32_t x = blockIdx.x & 7u, s = blockIdx.x >> 3;   // XCD, slot on that XCD
+    first = 2u * ((s >> 1) * 8u + x) + (s & 1u);
+    stride = gridDim.x;                                          // = 2 * number of pair workers
   } else {
-    auto st = [&](int t, int k, float2 v) { lds[PL::idx(t, k)] = v; };
-    fft_block<PL, true, true>(lds, tw, tid, ld, st);
-    __syncthreads();
-#pragma unroll 4
-    for (int v = tid; v < A * C; v += 1024) {
-      const int c = v % C, k2 = v / C;
-      float2 x = lds[PL::idx(c, k2)];
-      if (INV) x = make_float2(x.x * scale, -x.y * scale);
-      dst[(size_t)k2 * other + c0 + c] = x;
+    first = blockIdx.x;
+    stride = gridDim.x;
+  }
+  if (first >= n_items) return;
+
+  // MODE 1: the low twiddle table is gathered with a stride of n2 entries per lane: from global
+  // memory that is one 128-byte line per lane per load; from LDS it is an ordinary banked read
+  float2 *lo_lds = lds + PL::LDS_ELEMS;
+  if (MODE == 1) {
+    for (int i = threadIdx.x; i < (1 << kLoLog); i += 1024) lo_lds[i] = tw_lo[i];
+  }
+
+  float2 pre[16];
+  auto issue = [&](uint32_t item, int t) {
+    const uint32_t tile = item % tiles_per_xform, xf = item / tiles_per_xform;
+    const float2 *__restrict__ src = in + (size_t)xf * nfull + tile * C;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const int v = t + i * 1024, c = v % C, a = v / C;
+      pre[i] = src[(size_t)a * other + c];
     }
+  };
+  issue(first, threadIdx.x);
+
+  for (uint32_t item = first; item < n_items; item += stride) {
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));  // keep the per-thread address math inside the loop
+    const uint32_t tile = item % tiles_per_xform, xf = item / tiles_per_xform;
+    const uint32_t c0 = tile * C;
+    float2 *__restrict__ dst = out + (size_t)xf * nfull;
+    // ---- stage the prefetched A x C tile: element (row a, column c0 + c) -> sequence c, point a ----
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const int v = tid + i * 1024, c = v % C, a = v / C;
+      float2 x = pre[i];
+      if (MODE == 1 && INV) x.y = -x.y;  // inverse = conj(FFT(conj x)) / N
+      lds[PL::idx(c, a)] = x;
+    }
+    __syncthreads();
+    if (item + stride < n_items) issue(item + stride, tid);
+
+    auto ld = [&](int t, int e) -> float2 { return lds[PL::idx(t, e)]; };
+    if (MODE == 1) {
+      auto st = [&](int t, int k, float2 v) {
+        const uint32_t m = (c0 + (uint32_t)t) * (uint32_t)k;  // < N
+        const float2 w = cmul(lo_lds[m & ((1u << kLoLog) - 1)], tw_hi[m >> kLoLog]);
+        dst[(size_t)(c0 + t) * A + k] = cmul(v, w);
+      };
+      fft_block<PL, true, false>(lds, tw, tid, ld, st);
+    } else {
+      auto st = [&](int t, int k, float2 v) { lds[PL::idx(t, k)] = v; };
+      fft_block<PL, true, true>(lds, tw, tid, ld, st);
+      __syncthreads();
+#pragma unroll 4
+      for (int i = 0; i < 16; i++) {
+        const int v = tid + i * 1024, c = v % C, k2 = v / C;
+        float2 x = lds[PL::idx(c, k2)];
+        if (INV) x = make_float2(x.x * scale, -x.y * scale);
+        dst[(size_t)k2 * other + c0 + c] = x;
+      }
+    }
+    __syncthreads();  // LDS is free for the next tile
   }
 }
 
@@ -95,17 +138,26 @@ static hipError_t launch_pass(const float2 *in, float2 *out, const float2 *tw, c
                               int log_other, uint32_t batch, float scale, hipStream_t stream)
 {
   using PL = Plan<LOGA, 1024>;
+  const size_t lds_bytes = PL::LDS_BYTES + (MODE == 1 ? sizeof(float2) << kLoLog : 0);
   static bool attr_done[16] = {false};
   int dev = 0;
   (void)hipGetDevice(&dev);
   auto kern = fourstep_pass_kernel<LOGA, MODE, INV>;
   if (dev < 16 && !attr_done[dev]) {
-    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PL::LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
     attr_done[dev] = true;
   }
   const uint32_t tiles = (1u << log_other) / PL::TPB;
-  kern<<<tiles * batch, 1024, PL::LDS_BYTES, stream>>>(in, out, tw, tw_lo, tw_hi, log_other, tiles, scale);
+  const uint32_t n_items = tiles * batch;
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  // one resident workgroup per CU (LDS-limited).  Paired mapping needs whole pairs and a grid
+  // that is a multiple of 16 (two slots on each of the 8 XCDs).
+  uint32_t grid = n_items < (uint32_t)cus ? n_items : (uint32_t)cus;
+  const int paired = (tiles % 2 == 0 && grid >= 16) ? 1 : 0;
+  if (paired) grid &= ~15u;
+  kern<<<grid, 1024, lds_bytes, stream>>>(in, out, tw, tw_lo, tw_hi, log_other, tiles, n_items, paired, scale);
   return hipGetLastError();
 }
 
