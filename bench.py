@@ -48,7 +48,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="cfft_f32_4096x65536", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="cfft_f32_4096x65536",
+                    help="one of %s, or <cfft_f32|cfft_q15|cfft_q31|rfft_f32>_<N>x<batch> for tuning runs" % ", ".join(sorted(WORKLOADS)))
     ap.add_argument("--batch", type=int, default=0, help="override the batch (debug only; the line says so)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -220,7 +221,17 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert lib.arm_fft_mi355_set_device(local_rank) == 0, fft_amd.last_error()
 
-    wl = dict(WORKLOADS[args.workload])
+    if args.workload in WORKLOADS:
+        wl = dict(WORKLOADS[args.workload])
+    else:
+        import re
+        m = re.fullmatch(r"(cfft_f32|cfft_q15|cfft_q31|rfft_f32)_(\d+)x(\d+)", args.workload)
+        if not m:
+            raise SystemExit("unknown workload %r" % args.workload)
+        k = {"cfft_f32": "f32", "cfft_q15": "q15", "cfft_q31": "q31", "rfft_f32": "rfft"}[m.group(1)]
+        wl = dict(kind=k, n=int(m.group(2)), batch=int(m.group(3)), dtype={"rfft": "f32"}.get(k, k))
+        if k == "f32" and wl["n"] > 16384:
+            wl["kind"] = "large"
     if args.batch:
         wl["batch"] = args.batch
     kind, n, batch = wl["kind"], wl["n"], wl["batch"]
@@ -237,9 +248,9 @@ def main():
         amp = 2.0 ** -48
         data = ((torch.rand((batch, 2 * n), device="cuda", generator=gen) * 2 - 1) * amp).contiguous()
         step = lambda: lib.arm_cfft_f32_dev(ctypes.byref(S), ctypes.c_void_p(data.data_ptr()), batch, 0, 1, stream)
-        rescale = lambda: data.mul_(2.0 ** (-6 * chunk))
+        rescale = lambda: data.mul_(2.0 ** (-(int(np.log2(n)) // 2) * chunk))
         bytes_per_xform, flops_per_xform = 16 * n, 5.0 * n * np.log2(n)
-        kernel_name = "cfft_f32_kernel<12, false>"
+        kernel_name = "cfft_f32_kernel<%d, false>" % int(np.log2(n))
     elif kind == "large":
         S = fft_amd.arm_cfft_instance_u32_f32()
         assert lib.arm_cfft_init_u32_f32(ctypes.byref(S), n) == 0
@@ -249,10 +260,10 @@ def main():
         work = torch.empty_like(data)
         step = lambda: lib.arm_cfft_u32_f32_dev(ctypes.byref(S), ctypes.c_void_p(data.data_ptr()), ctypes.c_void_p(work.data_ptr()),
                                                 batch, 0, stream)
-        rescale = lambda: data.mul_(2.0 ** (-11 * chunk))
+        rescale = lambda: data.mul_(2.0 ** (-(int(np.log2(n)) // 2) * chunk))
         # algorithmic bytes per SURVEY 8(d): 16*N per transform; the four-step moves every point twice
         bytes_per_xform, flops_per_xform = 16 * n, 5.0 * n * np.log2(n)
-        kernel_name = "fourstep_pass_kernel<11, 1|2, false> (two launches per step)"
+        kernel_name = "fourstep_pass_kernel<%d|%d, 1|2, false> (two launches per step)" % ((int(np.log2(n)) + 1) // 2, int(np.log2(n)) // 2)
     elif kind == "gnss":
         n_ms, spc, spm = 10, 4, 4092
         prns = np.arange(1, 33, dtype=np.int32)
@@ -293,7 +304,7 @@ def main():
         step = lambda: fn(ctypes.byref(S), ctypes.c_void_p(data.data_ptr()), batch, 0, 1, stream)
         rescale, chunk = None, 1 << 30  # fixed point scales itself by 1/N per pass
         bytes_per_xform, flops_per_xform = (8 if kind == "q15" else 16) * n, 5.0 * n * np.log2(n)
-        kernel_name = "cfft_fixed_kernel<%s, 12, false>" % kind.upper()
+        kernel_name = "cfft_fixed_kernel<%s, %d, false>" % (kind.upper(), int(np.log2(n)))
     else:
         S = fft_amd.arm_rfft_fast_instance_f32()
         assert lib.arm_rfft_fast_init_f32(ctypes.byref(S), n) == 0
@@ -302,7 +313,7 @@ def main():
         step = lambda: lib.arm_rfft_fast_f32_dev(ctypes.byref(S), ctypes.c_void_p(data.data_ptr()), ctypes.c_void_p(out.data_ptr()), batch, 0, stream)
         rescale, chunk = None, 1 << 30
         bytes_per_xform, flops_per_xform = 8 * n, 2.5 * n * np.log2(n)
-        kernel_name = "rfft_f32_kernel<13, false>"
+        kernel_name = "rfft_f32_kernel<%d, false>" % (int(np.log2(n)) - 1)
 
     def barrier():
         if world > 1:
