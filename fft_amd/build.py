@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libarmfft_mi355.so")
 OBJDIR = os.path.join(HERE, "build")
-SOURCES = ["armfft_abi.cpp", "armfft_f32.hip", "armfft_fixed.hip", "armfft_large.hip", "armfft_gnss.hip"]
+SOURCES = ["armfft_abi.cpp", "armfft_f32.hip", "armfft_fixed.hip", "armfft_large.hip", "armfft_gnss.hip", "armfft_resamp.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-ffp-contract=fast"]
 

@@ -77,6 +77,7 @@ EXPORTED_SYMBOLS = (
     + ["arm_cfft_init_u32_f32", "arm_cfft_u32_f32_dev", "arm_cfft_u32_batch_f32"]
     + ["gnss_acq_plan_create", "gnss_acq_plan_destroy", "gnss_acq_plan_set_peak_separation", "gnss_acq_plan_code_spectra_dev",
        "gnss_acquire_dev", "gnss_acquire", "gnss_get_code_dev", "gnss_synth_gps_prn_dev", "gnss_find_top2_peaks_dev"]
+    + ["up_sample_N_to_M", "up_sample_10k_to_16k", "iq_resamp_zero_phase_dev", "iq_resamp_zero_phase_count"]
     + ["arm_fft_mi355_set_device", "arm_fft_mi355_warm", "arm_fft_mi355_last_error",
        "arm_fft_mi355_set_twiddle_rounding", "arm_fft_mi355_version"]
 )
@@ -142,6 +143,12 @@ def _load():
     L.gnss_get_code_dev.argtypes, L.gnss_get_code_dev.restype = [i32, i32, i32, c_void_p], c_int
     L.gnss_synth_gps_prn_dev.argtypes, L.gnss_synth_gps_prn_dev.restype = [i32, c_float, u32, c_void_p, i32], c_int
     L.gnss_find_top2_peaks_dev.argtypes, L.gnss_find_top2_peaks_dev.restype = [c_void_p, i32, i32, i32, u32, c_void_p, c_void_p], c_int
+    dbl = ctypes.c_double
+    L.up_sample_N_to_M.argtypes, L.up_sample_N_to_M.restype = [c_void_p, c_int, c_void_p, c_int], None
+    L.up_sample_10k_to_16k.argtypes, L.up_sample_10k_to_16k.restype = [c_void_p, c_void_p], None
+    L.iq_resamp_zero_phase_dev.argtypes = [dbl, dbl, i32, dbl, c_void_p, u32, c_void_p, u32, u32, POINTER(c_uint32), c_void_p]
+    L.iq_resamp_zero_phase_dev.restype = c_int
+    L.iq_resamp_zero_phase_count.argtypes, L.iq_resamp_zero_phase_count.restype = [dbl, dbl, i32, dbl, u32, u32], c_uint32
     L.arm_fft_mi355_set_device.argtypes, L.arm_fft_mi355_set_device.restype = [c_int], c_int
     L.arm_fft_mi355_warm.argtypes, L.arm_fft_mi355_warm.restype = [c_int, u32], c_int
     L.arm_fft_mi355_last_error.argtypes, L.arm_fft_mi355_last_error.restype = [], c_char_p

@@ -268,6 +268,22 @@ arm_status gnss_synth_gps_prn_dev(int32_t prn, float32_t doppler, uint32_t size,
 arm_status gnss_find_top2_peaks_dev(const float32_t *data_dev, int32_t is_complex, int32_t data_size, int32_t pk_sep, uint32_t batch,
                                     gnss_top2 *peaks_dev, void *stream);
 
+/* ---- zero-phase I/Q resampler ----
+ * Include/gnss_codes.h:97-99, bodies gnss_codes.c:868-904 over iq_resamp_zp_init /
+ * iq_resamp_process_zero_phase [Include/up_sample.h:20-24, up_sample.c:31-157].  `in`/`out` are
+ * the fork's c32 arrays (interleaved float I/Q, Include/cplx_types.h:9).  Same quirk as the
+ * reference: up_sample_N_to_M caps the output at llround(N_in * (M_out / N_in)) with the INTEGER
+ * quotient (gnss_codes.c:879), i.e. 10230 -> 16384 writes 10230 samples. */
+void up_sample_N_to_M(float32_t *in, int N_in, float32_t *out, int M_out);
+void up_sample_10k_to_16k(float32_t *in, float32_t *out);
+/* extension: the general routine on device pointers.  `batch` blocks, block b at
+ * in_dev + 2*n_in*b and out_dev + 2*n_out_cap*b; *n_out (optional) = samples written per block =
+ * min(llround(n_in * fout/fin), n_out_cap) (up_sample.c:121-125).  ntaps even, 4..64;
+ * 0 < cutoff <= 0.5 (up_sample.c:32-33).  Asynchronous on `stream`, allocates nothing. */
+arm_status iq_resamp_zero_phase_dev(double fin_hz, double fout_hz, int32_t ntaps, double cutoff, const float32_t *in_dev, uint32_t n_in,
+                                    float32_t *out_dev, uint32_t n_out_cap, uint32_t batch, uint32_t *n_out, void *stream);
+uint32_t iq_resamp_zero_phase_count(double fin_hz, double fout_hz, int32_t ntaps, double cutoff, uint32_t n_in, uint32_t n_out_cap);
+
 /* ---- library services (no counterpart in the reference) ---- */
 /* Select the GPU used by the calling thread's host-pointer entry points and build nothing else;
  * optional (device 0 / the current HIP device is used otherwise). */

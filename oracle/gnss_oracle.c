@@ -233,15 +233,16 @@ int orc_acquire_fused(const orc_c32 *signal, int n_ms, int spm, int fft_len, int
   return 0;
 }
 
-/* ---- resampler: iq_resamp_zp_* (up_sample.c:16-157) behind up_sample_N_to_M (gnss_codes.c:868-884) ---- */
-static double sinc_pi(double x) { return fabs(x) < 1e-12 ? 1.0 : sin(ORC_PI * x) / (ORC_PI * x); }
-static double blackman_sym(int n, int half)
+/* ---- resampler: iq_resamp_zp_* (up_sample.c:16-157) behind up_sample_N_to_M / up_sample_10k_to_16k
+ * (gnss_codes.c:868-904) ---- */
+static double sinc_pi(double x) { return fabs(x) < 1e-12 ? 1.0 : sin(ORC_PI * x) / (ORC_PI * x); } /* up_sample.c:16-20 */
+static double blackman_sym(int n, int half)                                                        /* :23-29 */
 {
   int N = 2 * half, k = n + half;
   double phi = (2.0 * ORC_PI * k) / (double)(N - 1);
   return 0.42 - 0.5 * cos(phi) + 0.08 * cos(2.0 * phi);
 }
-static int reflect_index(int idx, int N)
+static int reflect_index(int idx, int N) /* :51-59 */
 {
   if (N <= 1) return 0;
   while (idx < 0 || idx >= N) {
@@ -250,7 +251,7 @@ static int reflect_index(int idx, int N)
   }
   return idx;
 }
-static void resamp_forward(double dt, int half, double c, const orc_c32 *in, int nin, orc_c32 *out, int nout)
+static void resamp_forward(double dt, int half, double c, const orc_c32 *in, int nin, orc_c32 *out, int nout) /* :65-104 */
 {
   for (int k = 0; k < nout; k++) {
     double t = (double)k * dt;
@@ -258,7 +259,8 @@ static void resamp_forward(double dt, int half, double c, const orc_c32 *in, int
     double frac = t - (double)ti, ai = 0, aq = 0, ws = 0;
     for (int m = -half; m < half; m++) {
       double x = (double)m - frac;
-      double h = (2.0 * c) * sinc_pi(2.0 * c * x) * blackman_sym(m, half);
+      double h = (2.0 * c) * sinc_pi(2.0 * c * x);
+      h *= blackman_sym(m, half);
       int idx = reflect_index(ti + m, nin);
       ai += h * (double)in[idx].r;
       aq += h * (double)in[idx].i;
@@ -270,25 +272,45 @@ static void resamp_forward(double dt, int half, double c, const orc_c32 *in, int
   }
 }
 
-/* zero-phase N -> M resample, 12 taps, cutoff 0.45; n_out = llround(n_in * M/N) as in
- * iq_resamp_process_zero_phase (up_sample.c:115-157).  (up_sample_N_to_M's own cap uses the
- * INTEGER quotient M_out/N_in, gnss_codes.c:879, which truncates 10230->16384 to 10230 outputs;
- * the restatement follows up_sample_10k_to_16k's uncapped behaviour, :886-904.) */
-int orc_up_sample_n_to_m(const orc_c32 *in, int n_in, orc_c32 *out, int n_out)
+/* iq_resamp_zp_init + iq_resamp_process_zero_phase (up_sample.c:31-44, :115-157): forward
+ * resample fin -> fout, reverse, identity-rate pass of the same kernel, reverse.  Returns the
+ * number of outputs written = min(llround(n_in * fout / fin), cap); 0 on bad arguments. */
+long orc_iq_resamp_zero_phase(double fin, double fout, int ntaps, double cutoff, const orc_c32 *in, long n_in, orc_c32 *out,
+                              long cap)
 {
-  const int half = 6;
-  const double cutoff = 0.45;
-  if (n_in <= 0 || n_out <= 0) return 0;
+  if (ntaps < 4 || (ntaps & 1)) return 0;
+  if (!(cutoff > 0.0 && cutoff <= 0.5)) return 0;
+  if (!in || !out || n_in <= 0) return 0;
+  const int half = ntaps / 2;
+  long n_out = llround((double)n_in * (fout / fin));
+  if (n_out > cap) n_out = cap;
+  if (n_out <= 0) return 0;
   orc_c32 *y = (orc_c32 *)malloc(sizeof(orc_c32) * (size_t)n_out);
   orc_c32 *yr = (orc_c32 *)malloc(sizeof(orc_c32) * (size_t)n_out);
   orc_c32 *yr2 = (orc_c32 *)malloc(sizeof(orc_c32) * (size_t)n_out);
   if (!y || !yr || !yr2) return 0;
-  resamp_forward((double)n_in / (double)n_out, half, cutoff, in, n_in, y, n_out);
-  for (int k = 0; k < n_out; k++) yr[k] = y[n_out - 1 - k];
-  resamp_forward(1.0, half, cutoff, yr, n_out, yr2, n_out);
-  for (int k = 0; k < n_out; k++) out[k] = yr2[n_out - 1 - k];
+  resamp_forward(fin / fout, half, cutoff, in, (int)n_in, y, (int)n_out);
+  for (long k = 0; k < n_out; k++) yr[k] = y[n_out - 1 - k];
+  resamp_forward(1.0, half, cutoff, yr, (int)n_out, yr2, (int)n_out);
+  for (long k = 0; k < n_out; k++) out[k] = yr2[n_out - 1 - k];
   free(y);
   free(yr);
   free(yr2);
   return n_out;
+}
+
+/* up_sample_N_to_M (gnss_codes.c:868-884): 12 taps, cutoff 0.45, rates N_in and M_out; the cap is
+ * llround(N_in * (M_out / N_in)) with the INTEGER quotient (:879), so 10230 -> 16384 yields only
+ * 10230 outputs there.  Returns the number written. */
+long orc_up_sample_n_to_m(const orc_c32 *in, int n_in, orc_c32 *out, int m_out)
+{
+  if (n_in <= 0) return 0;
+  long cap = llround((double)((long)n_in * (long)(m_out / n_in)));
+  return orc_iq_resamp_zero_phase((double)n_in, (double)m_out, 12, 0.45, in, n_in, out, cap);
+}
+
+/* up_sample_10k_to_16k (gnss_codes.c:886-904): 10230 samples at 10.23 MHz -> 16384 at 16.384 MHz */
+long orc_up_sample_10k_to_16k(const orc_c32 *in, orc_c32 *out)
+{
+  return orc_iq_resamp_zero_phase(10230e3, 16384e3, 12, 0.45, in, 10230, out, llround(10230 * (16384e3 / 10230e3)) + 8);
 }
