@@ -117,33 +117,43 @@ struct Top2 {
 
 constexpr float kNoPeak = -1e10f;  // the reference's initial value (gnss_codes.c:1148)
 
-// order-preserving map float -> uint32 (find_top2_peaks_real may see negative samples)
-__device__ __forceinline__ unsigned ord_bits(float f)
+// second-peak candidate: larger value wins; on equal values the larger `ord` wins, with
+//   ord(A) = 1<<31 | position of the record that hands down << 15 | index   (latest A wins, A beats B)
+//   ord(B) =          (32767 - m) << 15 | m                                 (earliest B wins)
+// ord == 0 means "no candidate".
+struct Cand {
+  float v;
+  unsigned ord;
+};
+__device__ __forceinline__ Cand cand_better(Cand a, Cand b)
 {
-  const unsigned u = __float_as_uint(f);
-  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  const bool take_b = (b.ord != 0u) && ((a.ord == 0u) || (b.v > a.v) || (b.v == a.v && b.ord > a.ord));
+  return take_b ? b : a;
 }
-__device__ __forceinline__ float ord_float(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k); }
 
-// T threads, thread tid owns samples [tid*CH, tid*CH + CH) of mag(m) (m < n valid).  `xch` = LDS
-// scratch of >= 3 * (T/64) * 8 + 16 bytes not aliased with what mag() reads.  All threads return the result.
-template <int T, int CH, class Mag>
+// T threads, thread tid owns samples [tid*CH, tid*CH + CH) of mag(m) (m < n valid; FULL: n == T*CH).
+// `xch` = LDS scratch of >= 3 * (T/64) * 8 + 16 bytes not aliased with what mag() reads.  All
+// threads return the result.  Branch-free per sample: ~15 VALU operations.
+template <int T, int CH, bool FULL, class Mag>
 __device__ __forceinline__ Top2 top2_scan(Mag mag, int n, int sep, int tid, void *xch)
 {
   constexpr int NW = (T + 63) / 64;
   const int lane = tid & 63, wv = tid >> 6;
+  const int m0 = tid * CH;
   float x[CH];
   PrefixMax loc{kNoPeak, -1};
-  double sum = 0.0;
+  float fsum = 0.f;
 #pragma unroll
   for (int c = 0; c < CH; c++) {
-    const int m = tid * CH + c;
-    x[c] = m < n ? mag(m) : kNoPeak;
-    if (m < n) {
-      sum += (double)x[c];
-      loc = pm_combine(loc, PrefixMax{x[c], m});
-    }
+    const int m = m0 + c;
+    const bool ok = FULL || m < n;
+    x[c] = ok ? mag(m) : kNoPeak;
+    fsum += ok ? x[c] : 0.f;
+    const bool rec = ok && x[c] >= loc.v;
+    loc.v = rec ? x[c] : loc.v;
+    loc.i = rec ? m : loc.i;
   }
+  double sum = (double)fsum;
   // inclusive scan of the per-thread maxima over the wave, then over the waves
   PrefixMax inc = loc;
 #pragma unroll
@@ -153,10 +163,10 @@ __device__ __forceinline__ Top2 top2_scan(Mag mag, int n, int sep, int tid, void
   }
   PrefixMax exc{__shfl_up(inc.v, 1), __shfl_up(inc.i, 1)};
   if (lane == 0) exc = PrefixMax{kNoPeak, -1};
-  PrefixMax *wtot = reinterpret_cast<PrefixMax *>(xch);                          // [NW]
-  unsigned long long *wkey = reinterpret_cast<unsigned long long *>(wtot + NW);  // [NW]
-  double *wsum = reinterpret_cast<double *>(wkey + NW);                          // [NW]
-  if (lane == 63 || tid == T - 1) wtot[wv] = inc;
+  PrefixMax *wtot = reinterpret_cast<PrefixMax *>(xch);   // [NW]
+  Cand *wcand = reinterpret_cast<Cand *>(wtot + NW);       // [NW]
+  double *wsum = reinterpret_cast<double *>(wcand + NW);   // [NW]
+  if (lane == 63) wtot[wv] = inc;
   __syncthreads();
   PrefixMax before{kNoPeak, -1}, total{kNoPeak, -1};
 #pragma unroll
@@ -167,58 +177,48 @@ __device__ __forceinline__ Top2 top2_scan(Mag mag, int n, int sep, int tid, void
   }
   PrefixMax run = pm_combine(before, exc);  // state (v1, i1) seen by this thread's first sample
 
-  // walk the chunk, collect the best second-peak candidate as an ordered key
-  //   key = ordered value bits << 32 | A << 31 | order << 15 | index
-  //   A: order = position of the record that hands down;  B: order = 32767 - m (earliest wins)
-  unsigned long long key = 0;
+  // walk the chunk: every sample offers at most one candidate
+  Cand best{0.f, 0u};
+  const unsigned usep2 = 2u * (unsigned)sep;
 #pragma unroll
   for (int c = 0; c < CH; c++) {
-    const int m = tid * CH + c;
-    if (m < n) {
-      if (x[c] >= run.v) {
-        if (run.i != -1 && abs(m - run.i) > sep) {
-          const unsigned long long k = ((unsigned long long)ord_bits(run.v) << 32) | (1ull << 31) |
-                                       ((unsigned long long)m << 15) | (unsigned long long)run.i;
-          key = k > key ? k : key;
-        }
-        run = PrefixMax{x[c], m};
-      } else if (run.i != -1 && abs(m - run.i) > sep) {
-        const unsigned long long k = ((unsigned long long)ord_bits(x[c]) << 32) | ((unsigned long long)(32767 - m) << 15) |
-                                     (unsigned long long)m;
-        key = k > key ? k : key;
-      }
-    }
+    const int m = m0 + c;
+    const bool ok = FULL || m < n;
+    const bool rec = ok && x[c] >= run.v;
+    // |m - run.i| > sep  <=>  (unsigned)(m - run.i + sep) > 2 sep ; run.i == -1 (nothing seen yet) offers nothing
+    const bool far = ((unsigned)(m - run.i + sep) > usep2) && run.i != -1;
+    Cand k;
+    k.v = rec ? run.v : x[c];
+    k.ord = rec ? ((1u << 31) | ((unsigned)m << 15) | (unsigned)run.i) : (((unsigned)(32767 - m) << 15) | (unsigned)m);
+    if (!(ok && far)) k.ord = 0u;
+    best = cand_better(best, k);
+    run.v = rec ? x[c] : run.v;
+    run.i = rec ? m : run.i;
   }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {
-    const unsigned long long o = __shfl_xor(key, off);
-    key = o > key ? o : key;
+    Cand o{__shfl_xor(best.v, off), __shfl_xor(best.ord, off)};
+    best = cand_better(best, o);
     sum += __shfl_xor(sum, off);
   }
   if (lane == 0) {
-    wkey[wv] = key;
+    wcand[wv] = best;
     wsum[wv] = sum;
   }
   __syncthreads();
-  key = 0;
+  best = Cand{0.f, 0u};
   sum = 0.0;
 #pragma unroll
   for (int w = 0; w < NW; w++) {
-    const unsigned long long o = wkey[w];
-    key = o > key ? o : key;
+    best = cand_better(best, wcand[w]);
     sum += wsum[w];
   }
   Top2 r;
   r.v1 = total.v;
   r.i1 = total.i;
   r.sum = sum;
-  if (key) {
-    r.v2 = ord_float((unsigned)(key >> 32));
-    r.i2 = (int)(key & 0x7FFF);
-  } else {
-    r.v2 = kNoPeak;
-    r.i2 = -1;
-  }
+  r.v2 = best.ord ? best.v : kNoPeak;
+  r.i2 = best.ord ? (int)(best.ord & 0x7FFFu) : -1;
   return r;
 }
 
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void gnss_top2_kernel(const float *__restrict_
     }
     return row[m];
   };
-  const Top2 t = top2_scan<256, 64>(mag, n, sep, threadIdx.x, xch);  // n <= 16384
+  const Top2 t = top2_scan<256, 64, false>(mag, n, sep, threadIdx.x, xch);  // n <= 16384
   if (threadIdx.x == 0) {
     gnss_top2 r;
     r.val1 = t.v1;
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(GPlan<LOGN>::T, GPlan<LOGN>::T >= 1024 ? 4 : 3) voi
     fft_block_preloaded<PL, true>(v, lds, twt, lt, st);
     __syncthreads();
     auto mag = [&](int m) -> float { return magl[mag_idx(m)]; };
-    const Top2 t = top2_scan<T, 16>(mag, N, sep, lt, xch);
+    const Top2 t = top2_scan<T, 16, true>(mag, N, sep, lt, xch);
     if (lt == 0) finish_row(t, mag, N, d, prns[p], all + ((size_t)scene * n_prn + p) * n_dop + d);
     __syncthreads();  // the row is dead: the next IFFT may overwrite it
   }
