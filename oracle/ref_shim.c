@@ -111,3 +111,40 @@ int ref_cfft_radix2_f32(float *p, uint32_t N, uint32_t batch, int ifft, int bitr
   for (uint32_t b = 0; b < batch; b++) arm_cfft_radix2_f32(&S, p + (size_t)2 * N * b);
   return 0;
 }
+
+/* ---- arm_rfft_q15 / arm_rfft_q31 (arm_rfft_q15.c:148-182, arm_rfft_q31.c): instances filled by hand
+ * the way RFFTINIT_Q15/Q31 do (arm_rfft_init_q15.c:98-124), because arm_const_structs.c drags in
+ * every table of the library ---- */
+int ref_rfft_q15(int16_t *src, int16_t *dst, uint32_t n_real, int ifft, int bitrev)
+{
+  arm_cfft_instance_q15 C;
+  arm_rfft_instance_q15 S;
+  uint32_t mod = 8192u / n_real;
+  if (n_real < 32 || n_real > 8192 || (n_real & (n_real - 1)) || inst_q15(&C, n_real / 2)) return -1;
+  S.fftLenReal = n_real;
+  S.pTwiddleAReal = realCoefAQ15;
+  S.pTwiddleBReal = realCoefBQ15;
+  S.ifftFlagR = (uint8_t)ifft;
+  S.bitReverseFlagR = (uint8_t)bitrev;
+  S.twidCoefRModifier = mod;
+  S.pCfft = &C;
+  arm_rfft_q15(&S, src, dst);
+  return 0;
+}
+
+int ref_rfft_q31(int32_t *src, int32_t *dst, uint32_t n_real, int ifft, int bitrev)
+{
+  arm_cfft_instance_q31 C;
+  arm_rfft_instance_q31 S;
+  uint32_t mod = 8192u / n_real;
+  if (n_real < 32 || n_real > 8192 || (n_real & (n_real - 1)) || inst_q31(&C, n_real / 2)) return -1;
+  S.fftLenReal = n_real;
+  S.pTwiddleAReal = realCoefAQ31;
+  S.pTwiddleBReal = realCoefBQ31;
+  S.ifftFlagR = (uint8_t)ifft;
+  S.bitReverseFlagR = (uint8_t)bitrev;
+  S.twidCoefRModifier = mod;
+  S.pCfft = &C;
+  arm_rfft_q31(&S, src, dst);
+  return 0;
+}
