@@ -225,11 +225,11 @@ def main():
         wl = dict(WORKLOADS[args.workload])
     else:
         import re
-        m = re.fullmatch(r"(cfft_f32|cfft_q15|cfft_q31|rfft_f32)_(\d+)x(\d+)", args.workload)
+        m = re.fullmatch(r"(cfft_f32|cfft_q15|cfft_q31|rfft_f32|rfft_q15|rfft_q31)_(\d+)x(\d+)", args.workload)
         if not m:
             raise SystemExit("unknown workload %r" % args.workload)
-        k = {"cfft_f32": "f32", "cfft_q15": "q15", "cfft_q31": "q31", "rfft_f32": "rfft"}[m.group(1)]
-        wl = dict(kind=k, n=int(m.group(2)), batch=int(m.group(3)), dtype={"rfft": "f32"}.get(k, k))
+        k = {"cfft_f32": "f32", "cfft_q15": "q15", "cfft_q31": "q31", "rfft_f32": "rfft", "rfft_q15": "rq15", "rfft_q31": "rq31"}[m.group(1)]
+        wl = dict(kind=k, n=int(m.group(2)), batch=int(m.group(3)), dtype={"rfft": "f32", "rq15": "q15", "rq31": "q31"}.get(k, k))
         if k == "f32" and wl["n"] > 16384:
             wl["kind"] = "large"
     if args.batch:
@@ -294,6 +294,19 @@ def main():
         flops_per_xform = (len(dops) + rows_per_scene) * 5.0 * n * np.log2(n)
         bytes_per_xform = nn * 8 + rows_per_scene * 32                      # compulsory HBM bytes: signal in, tuples out
         kernel_name = "gnss_acquire_kernel<12>"
+    elif kind in ("rq15", "rq31"):
+        q = kind[1:]
+        S = (fft_amd.arm_rfft_instance_q15 if q == "q15" else fft_amd.arm_rfft_instance_q31)()
+        assert getattr(lib, "arm_rfft_init_" + q)(ctypes.byref(S), n, 0, 1) == 0
+        dt, amp = (torch.int16, 16384) if q == "q15" else (torch.int32, 2 ** 30)
+        data = torch.randint(-amp, amp, (batch, n), device="cuda", generator=gen, dtype=dt)
+        out = torch.zeros((batch, 2 * n), device="cuda", dtype=dt)
+        fn = getattr(lib, "arm_rfft_%s_dev" % q)
+        step = lambda: fn(ctypes.byref(S), ctypes.c_void_p(data.data_ptr()), ctypes.c_void_p(out.data_ptr()), batch, stream)
+        rescale, chunk = None, 1 << 30
+        sz = 2 if q == "q15" else 4
+        bytes_per_xform, flops_per_xform = 3 * n * sz, 2.5 * n * np.log2(n)      # n scalars in, 2n scalars out (spectrum + mirror)
+        kernel_name = "rfft_fixed_kernel<%s, %d, false>" % (q.upper(), int(np.log2(n)) - 1)
     elif kind in ("q15", "q31"):
         I = fft_amd.arm_cfft_instance_q15 if kind == "q15" else fft_amd.arm_cfft_instance_q31
         S = I()

@@ -6,7 +6,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int16, c_int3
 
 __all__ = [
     "lib", "lib_path", "ARM_MATH_SUCCESS", "ARM_MATH_ARGUMENT_ERROR",
-    "gnss_acq_result", "gnss_top2", "arm_cfft_radix2_instance_f32", "arm_cfft_instance_u32_f32", "arm_cfft_instance_f32", "arm_cfft_instance_q15", "arm_cfft_instance_q31", "arm_rfft_fast_instance_f32",
+    "arm_rfft_instance_q15", "arm_rfft_instance_q31", "gnss_acq_result", "gnss_top2", "arm_cfft_radix2_instance_f32", "arm_cfft_instance_u32_f32", "arm_cfft_instance_f32", "arm_cfft_instance_q15", "arm_cfft_instance_q31", "arm_rfft_fast_instance_f32",
     "last_error", "EXPORTED_SYMBOLS",
 ]
 
@@ -45,6 +45,16 @@ class arm_cfft_instance_u32_f32(Structure):
     _fields_ = [("fftLen", c_uint32)]
 
 
+class arm_rfft_instance_q15(Structure):
+    _fields_ = [("fftLenReal", c_uint32), ("ifftFlagR", c_uint8), ("bitReverseFlagR", c_uint8), ("twidCoefRModifier", c_uint32),
+                ("pTwiddleAReal", POINTER(c_int16)), ("pTwiddleBReal", POINTER(c_int16)), ("pCfft", POINTER(arm_cfft_instance_q15))]
+
+
+class arm_rfft_instance_q31(Structure):
+    _fields_ = [("fftLenReal", c_uint32), ("ifftFlagR", c_uint8), ("bitReverseFlagR", c_uint8), ("twidCoefRModifier", c_uint32),
+                ("pTwiddleAReal", POINTER(c_int32)), ("pTwiddleBReal", POINTER(c_int32)), ("pCfft", POINTER(arm_cfft_instance_q31))]
+
+
 class gnss_acq_result(Structure):
     _fields_ = [("peak", c_float), ("second", c_float), ("code_phase", c_int32), ("second_phase", c_int32),
                 ("doppler_bin", c_int32), ("prn", c_int32), ("snr_db", c_float), ("code_phase_interp", c_float)]
@@ -77,6 +87,9 @@ EXPORTED_SYMBOLS = (
     + ["arm_cfft_init_u32_f32", "arm_cfft_u32_f32_dev", "arm_cfft_u32_batch_f32"]
     + ["gnss_acq_plan_create", "gnss_acq_plan_destroy", "gnss_acq_plan_set_peak_separation", "gnss_acq_plan_code_spectra_dev",
        "gnss_acquire_dev", "gnss_acquire", "gnss_get_code_dev", "gnss_synth_gps_prn_dev", "gnss_find_top2_peaks_dev"]
+    + ["arm_rfft_init_q15", "arm_rfft_init_q31", "arm_rfft_q15", "arm_rfft_q31", "arm_rfft_batch_q15", "arm_rfft_batch_q31",
+       "arm_rfft_q15_dev", "arm_rfft_q31_dev"]
+    + ["arm_rfft_init_%d_%s" % (n, q) for n in (32, 64, 128, 256, 512, 1024, 2048, 4096, 8192) for q in ("q15", "q31")]
     + ["up_sample_N_to_M", "up_sample_10k_to_16k", "iq_resamp_zero_phase_dev", "iq_resamp_zero_phase_count"]
     + ["arm_fft_mi355_set_device", "arm_fft_mi355_warm", "arm_fft_mi355_last_error",
        "arm_fft_mi355_set_twiddle_rounding", "arm_fft_mi355_version"]
@@ -143,6 +156,18 @@ def _load():
     L.gnss_get_code_dev.argtypes, L.gnss_get_code_dev.restype = [i32, i32, i32, c_void_p], c_int
     L.gnss_synth_gps_prn_dev.argtypes, L.gnss_synth_gps_prn_dev.restype = [i32, c_float, u32, c_void_p, i32], c_int
     L.gnss_find_top2_peaks_dev.argtypes, L.gnss_find_top2_peaks_dev.restype = [c_void_p, i32, i32, i32, u32, c_void_p, c_void_p], c_int
+    for q, inst in (("q15", arm_rfft_instance_q15), ("q31", arm_rfft_instance_q31)):
+        f = getattr(L, "arm_rfft_init_" + q)
+        f.argtypes, f.restype = [POINTER(inst), u32, u32, u32], c_int
+        for n in (32, 64, 128, 256, 512, 1024, 2048, 4096, 8192):
+            f = getattr(L, "arm_rfft_init_%d_%s" % (n, q))
+            f.argtypes, f.restype = [POINTER(inst), u32, u32], c_int
+        f = getattr(L, "arm_rfft_" + q)
+        f.argtypes, f.restype = [POINTER(inst), c_void_p, c_void_p], None
+        f = getattr(L, "arm_rfft_batch_" + q)
+        f.argtypes, f.restype = [POINTER(inst), c_void_p, c_void_p, u32], c_int
+        f = getattr(L, "arm_rfft_%s_dev" % q)
+        f.argtypes, f.restype = [POINTER(inst), c_void_p, c_void_p, u32, c_void_p], c_int
     dbl = ctypes.c_double
     L.up_sample_N_to_M.argtypes, L.up_sample_N_to_M.restype = [c_void_p, c_int, c_void_p, c_int], None
     L.up_sample_10k_to_16k.argtypes, L.up_sample_10k_to_16k.restype = [c_void_p, c_void_p], None

@@ -176,6 +176,42 @@ static const int32_t *host_tw_q31(int logn)
   return t.data();
 }
 
+// realCoefA/B of arm_rfft_q15/q31 (Include/arm_common_tables.h:271-275: 8192 scalars = 4096 pairs, the
+// fork's 8192-point base).  Definitions are in the missing table blob; regenerated by the upstream rule
+//   A[2i] = 0.5 (1 - sin(2 pi i / 8192)), A[2i+1] = -0.5 cos(..), B[2i] = 0.5 (1 + sin(..)), B[2i+1] = 0.5 cos(..)
+// with round-half-away-from-zero to Q15 / Q31 and saturation (exact values at the quarter points).
+constexpr int kRealCoefPairs = 4096;
+struct RealCoef {
+  std::vector<int16_t> a15, b15;
+  std::vector<int32_t> a31, b31;
+};
+static const RealCoef &host_real_coef()
+{
+  static RealCoef rc;
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (rc.a15.empty()) {
+    rc.a15.resize(2 * kRealCoefPairs); rc.b15.resize(2 * kRealCoefPairs);
+    rc.a31.resize(2 * kRealCoefPairs); rc.b31.resize(2 * kRealCoefPairs);
+    auto fx = [](double v, double scale, double lo, double hi) { double r = round(v * scale); return r < lo ? lo : (r > hi ? hi : r); };
+    for (int i = 0; i < kRealCoefPairs; i++) {
+      double s, c;
+      if (i == 0) { s = 0.0; c = 1.0; }
+      else if (i == kRealCoefPairs / 2) { s = 1.0; c = 0.0; }
+      else { s = sin(2.0 * M_PI * (double)i / (2.0 * kRealCoefPairs)); c = cos(2.0 * M_PI * (double)i / (2.0 * kRealCoefPairs)); }
+      const double v[4] = {0.5 * (1.0 - s), 0.5 * (-1.0 * c), 0.5 * (1.0 + s), 0.5 * (1.0 * c)};
+      rc.a15[2 * i] = (int16_t)fx(v[0], 32768.0, -32768.0, 32767.0);
+      rc.a15[2 * i + 1] = (int16_t)fx(v[1], 32768.0, -32768.0, 32767.0);
+      rc.b15[2 * i] = (int16_t)fx(v[2], 32768.0, -32768.0, 32767.0);
+      rc.b15[2 * i + 1] = (int16_t)fx(v[3], 32768.0, -32768.0, 32767.0);
+      rc.a31[2 * i] = (int32_t)fx(v[0], 2147483648.0, -2147483648.0, 2147483647.0);
+      rc.a31[2 * i + 1] = (int32_t)fx(v[1], 2147483648.0, -2147483648.0, 2147483647.0);
+      rc.b31[2 * i] = (int32_t)fx(v[2], 2147483648.0, -2147483648.0, 2147483647.0);
+      rc.b31[2 * i + 1] = (int32_t)fx(v[3], 2147483648.0, -2147483648.0, 2147483647.0);
+    }
+  }
+  return rc;
+}
+
 // Swap-pair tables use 16-bit byte offsets (8 bytes per complex f32/q31 point), so they can only
 // describe N <= 8192; for 16384 the instance carries a NULL table and length 0 (the reference's
 // own 16384 table is declared uint32_t and unusable through this field, arm_common_tables.h:265).
@@ -252,6 +288,8 @@ struct DevPlans {
   int16_t *tw_q15[kMaxLog + 2] = {};
   int32_t *tw_q31[kMaxLog + 2] = {};
   float2 *tw_lo[kMaxLargeLog + 1] = {};
+  int16_t *rc15 = nullptr;  // realCoefA | realCoefB, 2 x 8192 q15
+  int32_t *rc31 = nullptr;
   void *stage = nullptr;  // grow-only staging buffers for the host-pointer entry points
   size_t stage_bytes = 0;
   void *stage2 = nullptr;
@@ -367,6 +405,49 @@ static const int32_t *dev_tw_q31(int logn)
   const int32_t *host = host_tw_q31(logn);
   std::lock_guard<std::mutex> lk(g_dev_mu);
   return dev_tw_fixed<int32_t>(g_dev[dev].tw_q31[logn], logn, host, launch_gen_twiddle_q31);
+}
+
+// device copies of realCoefA/B (A first, then B)
+template <typename T>
+static const T *dev_real_coef(T *&slot, const std::vector<T> &A, const std::vector<T> &B)
+{
+  if (!slot) {
+    T *p = nullptr;
+    const size_t n = A.size();
+    if (!hip_ok(hipMalloc((void **)&p, sizeof(T) * 2 * n), "hipMalloc(realCoef)")) return nullptr;
+    if (!hip_ok(hipMemcpy(p, A.data(), sizeof(T) * n, hipMemcpyHostToDevice), "hipMemcpy(realCoefA)") ||
+        !hip_ok(hipMemcpy(p + n, B.data(), sizeof(T) * n, hipMemcpyHostToDevice), "hipMemcpy(realCoefB)")) {
+      (void)hipFree(p);
+      return nullptr;
+    }
+    slot = p;
+  }
+  return slot;
+}
+static const int16_t *dev_rc15()
+{
+  int dev;
+  if (!current_device(&dev)) return nullptr;
+  const RealCoef &rc = host_real_coef();
+  std::lock_guard<std::mutex> lk(g_dev_mu);
+  return dev_real_coef<int16_t>(g_dev[dev].rc15, rc.a15, rc.b15);
+}
+static const int32_t *dev_rc31()
+{
+  int dev;
+  if (!current_device(&dev)) return nullptr;
+  const RealCoef &rc = host_real_coef();
+  std::lock_guard<std::mutex> lk(g_dev_mu);
+  return dev_real_coef<int32_t>(g_dev[dev].rc31, rc.a31, rc.b31);
+}
+
+// n_real = 32 .. 8192 (arm_rfft_init_q15.c:178-370; the fork's 16384 entry reuses modifier 1 on the
+// 8192-scalar tables, :152, and would read past them: refused)
+static int rfft_fixed_log(uint32_t n_real)
+{
+  if (!is_pow2(n_real)) return -1;
+  int l = ilog2u(n_real);
+  return (l >= 5 && l <= 13) ? l : -1;
 }
 
 // staging for host-pointer calls; serialised per device by g_stage_mu (these entry points are the
@@ -554,6 +635,132 @@ void arm_cfft_radix2_f32(const arm_cfft_radix2_instance_f32 *S, float32_t *pSrc)
   if (!S || cfft_log(S->fftLen) < 0) return;
   if (arm_cfft_radix2_batch_f32(S, pSrc, 1) != ARM_MATH_SUCCESS) {
     fprintf(stderr, "libarmfft_mi355: arm_cfft_radix2_f32 cannot run (%s)\n", t_err);
+    abort();
+  }
+}
+
+// ---------------- fixed-point real FFT (arm_rfft_q15 / arm_rfft_q31) ----------------
+// static complex instances the real instances point to (pCfft), one per size
+static const arm_cfft_instance_q15 *cfft_inst_q15(int logl)
+{
+  static arm_cfft_instance_q15 inst[kMaxLog + 1];
+  static std::once_flag once[kMaxLog + 1];
+  std::call_once(once[logl], [&] { (void)arm_cfft_init_q15(&inst[logl], (uint16_t)(1u << logl)); });
+  return &inst[logl];
+}
+static const arm_cfft_instance_q31 *cfft_inst_q31(int logl)
+{
+  static arm_cfft_instance_q31 inst[kMaxLog + 1];
+  static std::once_flag once[kMaxLog + 1];
+  std::call_once(once[logl], [&] { (void)arm_cfft_init_q31(&inst[logl], (uint16_t)(1u << logl)); });
+  return &inst[logl];
+}
+
+// arm_rfft_init_q15.c:98-124 (RFFTINIT_Q15) + :440-500 (length switch)
+arm_status arm_rfft_init_q15(arm_rfft_instance_q15 *S, uint32_t fftLenReal, uint32_t ifftFlagR, uint32_t bitReverseFlag)
+{
+  if (!S) return ARM_MATH_ARGUMENT_ERROR;
+  const int l = rfft_fixed_log(fftLenReal);
+  if (l < 0) return ARM_MATH_ARGUMENT_ERROR;
+  const RealCoef &rc = host_real_coef();
+  S->fftLenReal = fftLenReal;
+  S->pTwiddleAReal = rc.a15.data();
+  S->pTwiddleBReal = rc.b15.data();
+  S->ifftFlagR = (uint8_t)ifftFlagR;
+  S->bitReverseFlagR = (uint8_t)bitReverseFlag;
+  S->twidCoefRModifier = 8192u >> l;
+  S->pCfft = cfft_inst_q15(l - 1);
+  return ARM_MATH_SUCCESS;
+}
+arm_status arm_rfft_init_q31(arm_rfft_instance_q31 *S, uint32_t fftLenReal, uint32_t ifftFlagR, uint32_t bitReverseFlag)
+{
+  if (!S) return ARM_MATH_ARGUMENT_ERROR;
+  const int l = rfft_fixed_log(fftLenReal);
+  if (l < 0) return ARM_MATH_ARGUMENT_ERROR;
+  const RealCoef &rc = host_real_coef();
+  S->fftLenReal = fftLenReal;
+  S->pTwiddleAReal = rc.a31.data();
+  S->pTwiddleBReal = rc.b31.data();
+  S->ifftFlagR = (uint8_t)ifftFlagR;
+  S->bitReverseFlagR = (uint8_t)bitReverseFlag;
+  S->twidCoefRModifier = 8192u >> l;
+  S->pCfft = cfft_inst_q31(l - 1);
+  return ARM_MATH_SUCCESS;
+}
+#define ARMFFT_RFIX_INIT_N(N)                                                                                          \
+  arm_status arm_rfft_init_##N##_q15(arm_rfft_instance_q15 *S, uint32_t ifftFlagR, uint32_t bitReverseFlag) { return arm_rfft_init_q15(S, N, ifftFlagR, bitReverseFlag); } \
+  arm_status arm_rfft_init_##N##_q31(arm_rfft_instance_q31 *S, uint32_t ifftFlagR, uint32_t bitReverseFlag) { return arm_rfft_init_q31(S, N, ifftFlagR, bitReverseFlag); }
+ARMFFT_RFIX_INIT_N(32) ARMFFT_RFIX_INIT_N(64) ARMFFT_RFIX_INIT_N(128) ARMFFT_RFIX_INIT_N(256) ARMFFT_RFIX_INIT_N(512)
+ARMFFT_RFIX_INIT_N(1024) ARMFFT_RFIX_INIT_N(2048) ARMFFT_RFIX_INIT_N(4096) ARMFFT_RFIX_INIT_N(8192)
+
+arm_status arm_rfft_q15_dev(const arm_rfft_instance_q15 *S, const q15_t *pSrc, q15_t *pDst, uint32_t batch, void *stream)
+{
+  if (!S || !pSrc || !pDst) { set_error("arm_rfft_q15_dev: null argument"); return ARM_MATH_ARGUMENT_ERROR; }
+  const int l = rfft_fixed_log(S->fftLenReal);
+  if (l < 0) { set_error("arm_rfft_q15_dev: unsupported fftLenReal %u", S->fftLenReal); return ARM_MATH_ARGUMENT_ERROR; }
+  const int16_t *tw = dev_tw_q15(l - 1), *rc = dev_rc15();
+  if (!tw || !rc) return ARM_MATH_ARGUMENT_ERROR;
+  hipError_t e = launch_rfft_q15(l, pSrc, pDst, tw, rc, rc + 2 * kRealCoefPairs, (int)(8192u >> l), batch, S->ifftFlagR != 0,
+                                 S->bitReverseFlagR != 0, (hipStream_t)stream);
+  return hip_ok(e, "rfft_q15 launch") ? ARM_MATH_SUCCESS : ARM_MATH_ARGUMENT_ERROR;
+}
+arm_status arm_rfft_q31_dev(const arm_rfft_instance_q31 *S, const q31_t *pSrc, q31_t *pDst, uint32_t batch, void *stream)
+{
+  if (!S || !pSrc || !pDst) { set_error("arm_rfft_q31_dev: null argument"); return ARM_MATH_ARGUMENT_ERROR; }
+  const int l = rfft_fixed_log(S->fftLenReal);
+  if (l < 0) { set_error("arm_rfft_q31_dev: unsupported fftLenReal %u", S->fftLenReal); return ARM_MATH_ARGUMENT_ERROR; }
+  const int32_t *tw = dev_tw_q31(l - 1), *rc = dev_rc31();
+  if (!tw || !rc) return ARM_MATH_ARGUMENT_ERROR;
+  hipError_t e = launch_rfft_q31(l, pSrc, pDst, tw, rc, rc + 2 * kRealCoefPairs, (int)(8192u >> l), batch, S->ifftFlagR != 0,
+                                 S->bitReverseFlagR != 0, (hipStream_t)stream);
+  return hip_ok(e, "rfft_q31 launch") ? ARM_MATH_SUCCESS : ARM_MATH_ARGUMENT_ERROR;
+}
+
+// host pointers.  Forward: n_real scalars in, 2*n_real out per transform; inverse: n_real + 2 in, n_real out.
+extern "C++" {
+template <typename S, typename T>
+static arm_status rfft_fixed_host(const S *inst, const T *src, T *dst, uint32_t batch, arm_status (*dev_fn)(const S *, const T *, T *, uint32_t, void *))
+{
+  if (!inst || !src || !dst) { set_error("arm_rfft (fixed): null argument"); return ARM_MATH_ARGUMENT_ERROR; }
+  if (rfft_fixed_log(inst->fftLenReal) < 0) { set_error("arm_rfft (fixed): unsupported fftLenReal %u", inst->fftLenReal); return ARM_MATH_ARGUMENT_ERROR; }
+  if (batch == 0) return ARM_MATH_SUCCESS;
+  int dev;
+  if (!current_device(&dev)) return ARM_MATH_ARGUMENT_ERROR;
+  const size_t n = inst->fftLenReal;
+  const size_t in_elems = (inst->ifftFlagR ? n + 2 : n) * batch, out_elems = (inst->ifftFlagR ? n : 2 * n) * batch;
+  std::lock_guard<std::mutex> lk(g_stage_mu);
+  T *di = (T *)stage_buffer(dev, in_elems * sizeof(T), 0), *dout = (T *)stage_buffer(dev, out_elems * sizeof(T), 1);
+  if (!di || !dout) return ARM_MATH_ARGUMENT_ERROR;
+  if (!hip_ok(hipMemcpy(di, src, in_elems * sizeof(T), hipMemcpyHostToDevice), "hipMemcpy(H2D)")) return ARM_MATH_ARGUMENT_ERROR;
+  arm_status s = dev_fn(inst, di, dout, batch, nullptr);
+  if (s != ARM_MATH_SUCCESS) return s;
+  if (!hip_ok(hipMemcpy(dst, dout, out_elems * sizeof(T), hipMemcpyDeviceToHost), "hipMemcpy(D2H)")) return ARM_MATH_ARGUMENT_ERROR;
+  return ARM_MATH_SUCCESS;
+}
+}  // extern "C++"
+arm_status arm_rfft_batch_q15(const arm_rfft_instance_q15 *S, const q15_t *pSrc, q15_t *pDst, uint32_t batch)
+{
+  return rfft_fixed_host<arm_rfft_instance_q15, q15_t>(S, pSrc, pDst, batch, arm_rfft_q15_dev);
+}
+arm_status arm_rfft_batch_q31(const arm_rfft_instance_q31 *S, const q31_t *pSrc, q31_t *pDst, uint32_t batch)
+{
+  return rfft_fixed_host<arm_rfft_instance_q31, q31_t>(S, pSrc, pDst, batch, arm_rfft_q31_dev);
+}
+// arm_rfft_q15.c:148-182 / arm_rfft_q31.c.  Unlike the reference, pSrc is left intact in the forward
+// direction (the reference runs the complex FFT in place on it).
+void arm_rfft_q15(const arm_rfft_instance_q15 *S, q15_t *pSrc, q15_t *pDst)
+{
+  if (!S || rfft_fixed_log(S->fftLenReal) < 0) return;
+  if (arm_rfft_batch_q15(S, pSrc, pDst, 1) != ARM_MATH_SUCCESS) {
+    fprintf(stderr, "libarmfft_mi355: arm_rfft_q15 cannot run (%s)\n", t_err);
+    abort();
+  }
+}
+void arm_rfft_q31(const arm_rfft_instance_q31 *S, q31_t *pSrc, q31_t *pDst)
+{
+  if (!S || rfft_fixed_log(S->fftLenReal) < 0) return;
+  if (arm_rfft_batch_q31(S, pSrc, pDst, 1) != ARM_MATH_SUCCESS) {
+    fprintf(stderr, "libarmfft_mi355: arm_rfft_q31 cannot run (%s)\n", t_err);
     abort();
   }
 }

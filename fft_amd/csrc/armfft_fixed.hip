@@ -530,4 +530,243 @@ hipError_t launch_cfft_q31(int logn, int32_t *data, const int32_t *tw, uint32_t 
   return launch_fixed<Q31>(logn, reinterpret_cast<int2 *>(data), reinterpret_cast<const int2 *>(tw), batch, inverse, bitrev, stream);
 }
 
+// ------------------------------------------------------------------------------------------
+// fixed-point REAL FFT: arm_rfft_q15 (arm_rfft_q15.c:148-182) / arm_rfft_q31 (arm_rfft_q31.c, the
+// non-Neon body), generic-C split functions arm_split_rfft_* / arm_split_rifft_* restated bit for
+// bit and fused around the in-LDS complex transform of L = n_real/2 points:
+//   forward:  load L complex -> cfft -> split from LDS -> 2L complex words out (spectrum + mirror)
+//   inverse:  split_rifft while loading (reads L+1 complex) -> inverse cfft -> saturating << 1 on store
+// A/B = realCoefA/B tables (8192 scalars, 4096 pairs), mod = twidCoefRModifier.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int32_t mult_r(int32_t x, int32_t y) { return (int32_t)(((long long)x * y + 0x80000000LL) >> 32); }
+__device__ __forceinline__ int32_t macc_r(int32_t a, int32_t x, int32_t y)
+{
+  return (int32_t)((long long)(((unsigned long long)(long long)a << 32) + (unsigned long long)((long long)x * y) + 0x80000000ULL) >> 32);
+}
+__device__ __forceinline__ int32_t msub_r(int32_t a, int32_t x, int32_t y)
+{
+  return (int32_t)((long long)(((unsigned long long)(long long)a << 32) - (unsigned long long)((long long)x * y) + 0x80000000ULL) >> 32);
+}
+
+// forward split of bin i (1 <= i < L) from s1 = X[i], s2 = X[L-i]; returns the word for position i;
+// the mirrored position 2L - i holds (re, -im)
+__device__ __forceinline__ Q15::cpx split_fwd(Q15::cpx s1, Q15::cpx s2, Q15::cpx a, Q15::cpx b)
+{
+  int32_t outR = s1.re * a.re;
+  outR = wsub(outR, s1.im * a.im);
+  outR = wadd(outR, s2.re * b.re);
+  outR = wadd(outR, s2.im * b.im) >> 16;
+  int32_t outI = s2.re * b.im;
+  outI = wsub(outI, s2.im * b.re);
+  outI = wadd(outI, s1.im * a.re);
+  outI = wadd(outI, s1.re * a.im);
+  return Q15::cpx{(int16_t)outR, (int16_t)(outI >> 16)};
+}
+__device__ __forceinline__ Q31::cpx split_fwd(Q31::cpx s1, Q31::cpx s2, Q31::cpx a, Q31::cpx b)
+{
+  const int32_t A1 = a.re, A2 = a.im, B1 = b.re;
+  int32_t outR = mult_r(s1.re, A1);
+  int32_t outI = mult_r(s1.re, A2);
+  outR = msub_r(outR, s1.im, A2);
+  outI = macc_r(outI, s1.im, A1);
+  outR = msub_r(outR, s2.im, A2);
+  outI = msub_r(outI, s2.im, B1);
+  outR = macc_r(outR, s2.re, B1);
+  outI = msub_r(outI, s2.re, A2);
+  return Q31::cpx{outR, outI};
+}
+__device__ __forceinline__ Q15::cpx mirror(Q15::cpx v) { return Q15::cpx{v.re, (int16_t)(-(int)v.im)}; }
+__device__ __forceinline__ Q31::cpx mirror(Q31::cpx v) { return Q31::cpx{v.re, (int32_t)(0u - (uint32_t)v.im)}; }
+// DC / Nyquist words: ((re + im) >> 1, 0) and ((re - im) >> 1, 0)
+__device__ __forceinline__ Q15::cpx dc_word(Q15::cpx x, bool nyq)
+{
+  const int v = nyq ? ((int)x.re - (int)x.im) : ((int)x.re + (int)x.im);
+  return Q15::cpx{(int16_t)(v >> 1), 0};
+}
+__device__ __forceinline__ Q31::cpx dc_word(Q31::cpx x, bool nyq)
+{
+  const int32_t v = nyq ? wsub(x.re, x.im) : wadd(x.re, x.im);
+  return Q31::cpx{v >> 1, 0};
+}
+// inverse split of point i (0 <= i < L) from s1 = X[i], s2 = X[L-i]
+__device__ __forceinline__ Q15::cpx split_inv(Q15::cpx s1, Q15::cpx s2, Q15::cpx a, Q15::cpx b)
+{
+  int32_t outR = s2.re * b.re;
+  outR = wsub(outR, s2.im * b.im);
+  outR = wadd(outR, s1.re * a.re);
+  outR = wadd(outR, s1.im * a.im) >> 16;
+  int32_t outI = s1.im * a.re;
+  outI = wsub(outI, s1.re * a.im);
+  outI = wsub(outI, s2.re * b.im);
+  outI = wsub(outI, s2.im * b.re);
+  return Q15::cpx{(int16_t)outR, (int16_t)(outI >> 16)};
+}
+__device__ __forceinline__ Q31::cpx split_inv(Q31::cpx s1, Q31::cpx s2, Q31::cpx a, Q31::cpx b)
+{
+  const int32_t A1 = a.re, A2 = a.im, B1 = b.re;
+  int32_t outR = mult_r(s1.re, A1);
+  int32_t outI = mult_r(s1.re, (int32_t)(0u - (uint32_t)A2));
+  outR = macc_r(outR, s1.im, A2);
+  outI = macc_r(outI, s1.im, A1);
+  outR = macc_r(outR, s2.im, A2);
+  outI = msub_r(outI, s2.im, B1);
+  outR = macc_r(outR, s2.re, B1);
+  outI = macc_r(outI, s2.re, A2);
+  return Q31::cpx{outR, outI};
+}
+// arm_shift_q15 / arm_shift_q31 by +1: saturating
+__device__ __forceinline__ Q15::cpx sat_shl1(Q15::cpx v) { return Q15::cpx{(int16_t)ssat16((int)v.re << 1), (int16_t)ssat16((int)v.im << 1)}; }
+__device__ __forceinline__ int32_t sat_dbl(int32_t x)
+{
+  const long long v = (long long)x * 2;
+  return v > 2147483647LL ? 2147483647 : (v < -2147483648LL ? (int32_t)0x80000000 : (int32_t)v);
+}
+__device__ __forceinline__ Q31::cpx sat_shl1(Q31::cpx v) { return Q31::cpx{sat_dbl(v.re), sat_dbl(v.im)}; }
+
+// LOGN = log2(L).  Forward: in = L words per transform, out = 2L words.  Inverse: in = L + 1 words per
+// transform (stride L + 1), out = L words.
+template <class Q, int LOGN, bool INV>
+__global__ __launch_bounds__(FixedPlan<LOGN>::T, 4) void rfft_fixed_kernel(const typename Q::word *__restrict__ in,
+                                                                          typename Q::word *__restrict__ out,
+                                                                          const typename Q::tword *__restrict__ tw,
+                                                                          const typename Q::tword *__restrict__ coefA,
+                                                                          const typename Q::tword *__restrict__ coefB, int mod,
+                                                                          uint32_t batch, uint32_t ngroups, int bitrev)
+{
+  using PL = FixedPlan<LOGN>;
+  using word = typename Q::word;
+  using cpx = typename Q::cpx;
+  constexpr int L = PL::N;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  word *lds = reinterpret_cast<word *>(lds_raw);
+  const int tid = threadIdx.x;
+  const uint32_t g = blockIdx.x + blockIdx.y * gridDim.x;
+  if (g >= ngroups) return;
+  const uint32_t tr0 = g * PL::TPB;
+  const uint32_t nvt = (batch - tr0) >= (uint32_t)PL::TPB ? (uint32_t)PL::TPB : (batch - tr0);  // valid transforms here
+
+  // ---- load ----
+  if (!INV) {
+    const word *__restrict__ src = in + (size_t)tr0 * L;
+    for (int e = tid; e < PL::ELEMS; e += PL::T) lds[fpad(e)] = ((uint32_t)(e >> LOGN) < nvt) ? src[e] : word{};
+  } else {
+    for (int e = tid; e < PL::ELEMS; e += PL::T) {
+      const int t = e >> LOGN, i = e & (L - 1);
+      word w{};
+      if ((uint32_t)t < nvt) {
+        const word *__restrict__ src = in + (size_t)(tr0 + t) * (L + 1);
+        const cpx s1 = Q::unpack(src[i]), s2 = Q::unpack(src[L - i]);
+        w = Q::pack(split_inv(s1, s2, Q::unpack(coefA[i * mod]), Q::unpack(coefB[i * mod])));
+      }
+      lds[fpad(e)] = w;
+    }
+  }
+  __syncthreads();
+
+  // ---- complex transform of L points, exactly as cfft_fixed_kernel ----
+  if constexpr (PL::BY2) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int u = tid + k * PL::T;
+      const int t = u >> (LOGN - 1), i = u & (PL::L - 1);
+      const int ea = t * PL::N + i, eb = ea + PL::L;
+      cpx a = Q::unpack(lds[fpad(ea)]), b = Q::unpack(lds[fpad(eb)]);
+      by2<Q, INV>(a, b, Q::unpack(tw[i]));
+      lds[fpad(ea)] = Q::pack(a);
+      lds[fpad(eb)] = Q::pack(b);
+    }
+    __syncthreads();
+  }
+  {
+    const int sub = tid >> (PL::LOGL - 4), r = tid & ((PL::L >> 4) - 1);
+    run_stages<Q, PL::LOGL, 0, INV, PL::BY2 ? 2 : 1>(lds, tw, sub * PL::L, r);
+  }
+  // bin i of transform t as arm_cfft_* leaves it (bit reversal and the radix4by2 final << 1 folded in)
+  auto X = [&](int t, int i) -> cpx {
+    const int src = bitrev ? (int)(__brev((unsigned)i) >> (32 - LOGN)) : i;
+    cpx c = Q::unpack(lds[fpad(t * L + src)]);
+    if (PL::BY2) c = shl1<Q>(c);
+    return c;
+  };
+
+  // ---- store ----
+  if (!INV) {
+    word *__restrict__ dst = out + (size_t)tr0 * (2 * L);
+    for (int e = tid; e < 2 * PL::ELEMS; e += PL::T) {
+      const int t = e >> (LOGN + 1), k = e & (2 * L - 1);
+      if ((uint32_t)t >= nvt) continue;
+      cpx o;
+      if (k == 0 || k == L) {
+        o = dc_word(X(t, 0), k == L);
+      } else {
+        const int i = k < L ? k : 2 * L - k;
+        o = split_fwd(X(t, i), X(t, L - i), Q::unpack(coefA[i * mod]), Q::unpack(coefB[i * mod]));
+        if (k > L) o = mirror(o);
+      }
+      dst[e] = Q::pack(o);
+    }
+  } else {
+    word *__restrict__ dst = out + (size_t)tr0 * L;
+    for (int e = tid; e < PL::ELEMS; e += PL::T) {
+      const int t = e >> LOGN, i = e & (L - 1);
+      if ((uint32_t)t < nvt) dst[e] = Q::pack(sat_shl1(X(t, i)));
+    }
+  }
+}
+
+template <class Q, int LOGN, bool INV>
+static hipError_t launch_rfft_fixed_one(const typename Q::word *in, typename Q::word *out, const typename Q::tword *tw,
+                                        const typename Q::tword *A, const typename Q::tword *B, int mod, uint32_t batch, bool bitrev,
+                                        hipStream_t stream)
+{
+  using PL = FixedPlan<LOGN>;
+  constexpr size_t lds_bytes = (size_t)PL::LDS_WORDS * sizeof(typename Q::word);
+  static bool attr_done[16] = {false};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  auto kern = rfft_fixed_kernel<Q, LOGN, INV>;
+  if (lds_bytes > 48 * 1024 && dev < 16 && !attr_done[dev]) {
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+    attr_done[dev] = true;
+  }
+  const uint32_t ngroups = (batch + PL::TPB - 1) / PL::TPB;
+  const uint32_t gx = ngroups < 65536u ? ngroups : 65536u;
+  kern<<<dim3(gx, (ngroups + gx - 1) / gx, 1), PL::T, lds_bytes, stream>>>(in, out, tw, A, B, mod, batch, ngroups, bitrev ? 1 : 0);
+  return hipGetLastError();
+}
+
+template <class Q>
+static hipError_t launch_rfft_fixed(int logl, const typename Q::word *in, typename Q::word *out, const typename Q::tword *tw,
+                                    const typename Q::tword *A, const typename Q::tword *B, int mod, uint32_t batch, bool inverse,
+                                    bool bitrev, hipStream_t stream)
+{
+  if (batch == 0) return hipSuccess;
+  switch (logl) {
+#define C(L) \
+  case L:    \
+    return inverse ? launch_rfft_fixed_one<Q, L, true>(in, out, tw, A, B, mod, batch, bitrev, stream) \
+                   : launch_rfft_fixed_one<Q, L, false>(in, out, tw, A, B, mod, batch, bitrev, stream);
+    C(4) C(5) C(6) C(7) C(8) C(9) C(10) C(11) C(12)
+#undef C
+  }
+  return hipErrorInvalidValue;
+}
+
+hipError_t launch_rfft_q15(int logn_real, const int16_t *in, int16_t *out, const int16_t *tw, const int16_t *A, const int16_t *B, int mod,
+                           uint32_t batch, bool inverse, bool bitrev, hipStream_t stream)
+{
+  return launch_rfft_fixed<Q15>(logn_real - 1, reinterpret_cast<const uint32_t *>(in), reinterpret_cast<uint32_t *>(out),
+                                reinterpret_cast<const uint32_t *>(tw), reinterpret_cast<const uint32_t *>(A),
+                                reinterpret_cast<const uint32_t *>(B), mod, batch, inverse, bitrev, stream);
+}
+
+hipError_t launch_rfft_q31(int logn_real, const int32_t *in, int32_t *out, const int32_t *tw, const int32_t *A, const int32_t *B, int mod,
+                           uint32_t batch, bool inverse, bool bitrev, hipStream_t stream)
+{
+  return launch_rfft_fixed<Q31>(logn_real - 1, reinterpret_cast<const int2 *>(in), reinterpret_cast<int2 *>(out),
+                                reinterpret_cast<const int2 *>(tw), reinterpret_cast<const int2 *>(A), reinterpret_cast<const int2 *>(B),
+                                mod, batch, inverse, bitrev, stream);
+}
+
 }  // namespace armfft

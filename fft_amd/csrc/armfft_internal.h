@@ -33,6 +33,14 @@ hipError_t launch_cfft_q15(int logn, int16_t *data, const int16_t *tw, uint32_t 
 hipError_t launch_cfft_q31(int logn, int32_t *data, const int32_t *tw, uint32_t batch, bool inverse, bool bitrev,
                            hipStream_t stream);
 
+// fixed-point real FFT, n_real = 2^logn_real (32..8192); tw = table of the n_real/2-point complex
+// transform, A/B = realCoefA/B (8192 scalars), mod = 8192 / n_real.  Forward: in n_real scalars per
+// transform, out 2*n_real.  Inverse: in n_real + 2 scalars per transform, out n_real.
+hipError_t launch_rfft_q15(int logn_real, const int16_t *in, int16_t *out, const int16_t *tw, const int16_t *A, const int16_t *B, int mod,
+                           uint32_t batch, bool inverse, bool bitrev, hipStream_t stream);
+hipError_t launch_rfft_q31(int logn_real, const int32_t *in, int32_t *out, const int32_t *tw, const int32_t *A, const int32_t *B, int mod,
+                           uint32_t batch, bool inverse, bool bitrev, hipStream_t stream);
+
 // large complex f32 (2^15..2^22), four-step: data -> work -> data
 hipError_t launch_cfft_large_f32(int logn, float2 *data, float2 *work, const float2 *tw1, const float2 *tw2,
                                  const float2 *tw_lo, const float2 *tw_hi, uint32_t batch, bool inverse, hipStream_t stream);

@@ -170,6 +170,63 @@ arm_status arm_rfft_fast_batch_f32(const arm_rfft_fast_instance_f32 *S, float32_
 arm_status arm_rfft_fast_f32_dev(const arm_rfft_fast_instance_f32 *S, const float32_t *p_dev, float32_t *pOut_dev,
                                  uint32_t batch, uint8_t ifftFlag, void *stream);
 
+/* ---- fixed-point real FFT ---- */
+/* Include/dsp/transform_functions.h:513-526 (non-Neon, non-MVE layout) */
+typedef struct {
+  uint32_t fftLenReal;
+  uint8_t ifftFlagR;
+  uint8_t bitReverseFlagR;
+  uint32_t twidCoefRModifier;
+  const q15_t *pTwiddleAReal;
+  const q15_t *pTwiddleBReal;
+  const arm_cfft_instance_q15 *pCfft;
+} arm_rfft_instance_q15;
+/* same for q31 (transform_functions.h, arm_rfft_instance_q31) */
+typedef struct {
+  uint32_t fftLenReal;
+  uint8_t ifftFlagR;
+  uint8_t bitReverseFlagR;
+  uint32_t twidCoefRModifier;
+  const q31_t *pTwiddleAReal;
+  const q31_t *pTwiddleBReal;
+  const arm_cfft_instance_q31 *pCfft;
+} arm_rfft_instance_q31;
+/* arm_rfft_init_q15.c:98-124 and the length switch at its end; arm_rfft_init_q31.c likewise.
+ * fftLenReal 32 .. 8192.  16384 is refused: the fork's entry (arm_rfft_init_q15.c:152, "fixme" in
+ * arm_rfft_init_q31.c:150) reuses modifier 1 on the 8192-scalar realCoef tables and reads past them. */
+arm_status arm_rfft_init_q15(arm_rfft_instance_q15 *S, uint32_t fftLenReal, uint32_t ifftFlagR, uint32_t bitReverseFlag);
+arm_status arm_rfft_init_q31(arm_rfft_instance_q31 *S, uint32_t fftLenReal, uint32_t ifftFlagR, uint32_t bitReverseFlag);
+arm_status arm_rfft_init_32_q15(arm_rfft_instance_q15 *S, uint32_t ifftFlagR, uint32_t bitReverseFlag);
+arm_status arm_rfft_init_64_q15(arm_rfft_instance_q15 *S, uint32_t ifftFlagR, uint32_t bitReverseFlag);
+arm_status arm_rfft_init_128_q15(arm_rfft_instance_q15 *S, uint32_t ifftFlagR, uint32_t bitReverseFlag);
+arm_status arm_rfft_init_256_q15(arm_rfft_instance_q15 *S, uint32_t ifftFlagR, uint32_t bitReverseFlag);
+arm_status arm_rfft_init_512_q15(arm_rfft_instance_q15 *S, uint32_t ifftFlagR, uint32_t bitReverseFlag);
+arm_status arm_rfft_init_1024_q15(arm_rfft_instance_q15 *S, uint32_t ifftFlagR, uint32_t bitReverseFlag);
+arm_status arm_rfft_init_2048_q15(arm_rfft_instance_q15 *S, uint32_t ifftFlagR, uint32_t bitReverseFlag);
+arm_status arm_rfft_init_4096_q15(arm_rfft_instance_q15 *S, uint32_t ifftFlagR, uint32_t bitReverseFlag);
+arm_status arm_rfft_init_8192_q15(arm_rfft_instance_q15 *S, uint32_t ifftFlagR, uint32_t bitReverseFlag);
+arm_status arm_rfft_init_32_q31(arm_rfft_instance_q31 *S, uint32_t ifftFlagR, uint32_t bitReverseFlag);
+arm_status arm_rfft_init_64_q31(arm_rfft_instance_q31 *S, uint32_t ifftFlagR, uint32_t bitReverseFlag);
+arm_status arm_rfft_init_128_q31(arm_rfft_instance_q31 *S, uint32_t ifftFlagR, uint32_t bitReverseFlag);
+arm_status arm_rfft_init_256_q31(arm_rfft_instance_q31 *S, uint32_t ifftFlagR, uint32_t bitReverseFlag);
+arm_status arm_rfft_init_512_q31(arm_rfft_instance_q31 *S, uint32_t ifftFlagR, uint32_t bitReverseFlag);
+arm_status arm_rfft_init_1024_q31(arm_rfft_instance_q31 *S, uint32_t ifftFlagR, uint32_t bitReverseFlag);
+arm_status arm_rfft_init_2048_q31(arm_rfft_instance_q31 *S, uint32_t ifftFlagR, uint32_t bitReverseFlag);
+arm_status arm_rfft_init_4096_q31(arm_rfft_instance_q31 *S, uint32_t ifftFlagR, uint32_t bitReverseFlag);
+arm_status arm_rfft_init_8192_q31(arm_rfft_instance_q31 *S, uint32_t ifftFlagR, uint32_t bitReverseFlag);
+/* arm_rfft_q15.c:148-182 (split functions :352-405, :552-579), arm_rfft_q31.c (non-Neon body).
+ * Forward (ifftFlagR 0): fftLenReal scalars in, 2*fftLenReal scalars out (spectrum and its mirror),
+ * down-scaled as documented there.  Inverse: fftLenReal + 2 scalars read, fftLenReal written.
+ * Bit-exact with the reference's generic-C branch; pSrc is NOT clobbered (the reference's forward
+ * path transforms it in place). */
+void arm_rfft_q15(const arm_rfft_instance_q15 *S, q15_t *pSrc, q15_t *pDst);
+void arm_rfft_q31(const arm_rfft_instance_q31 *S, q31_t *pSrc, q31_t *pDst);
+/* extensions: batch (transform b at pSrc + in_len*b, pDst + out_len*b with the lengths above) */
+arm_status arm_rfft_batch_q15(const arm_rfft_instance_q15 *S, const q15_t *pSrc, q15_t *pDst, uint32_t batch);
+arm_status arm_rfft_batch_q31(const arm_rfft_instance_q31 *S, const q31_t *pSrc, q31_t *pDst, uint32_t batch);
+arm_status arm_rfft_q15_dev(const arm_rfft_instance_q15 *S, const q15_t *pSrc_dev, q15_t *pDst_dev, uint32_t batch, void *stream);
+arm_status arm_rfft_q31_dev(const arm_rfft_instance_q31 *S, const q31_t *pSrc_dev, q31_t *pDst_dev, uint32_t batch, void *stream);
+
 /* ---- f32 complex FFT, deprecated radix-2 API (what the fork's fft_c32 calls, CMSIS/CMSIS.cpp:218-234) ---- */
 /* Include/dsp/transform_functions.h:217-227 */
 typedef struct {

@@ -17,7 +17,7 @@ from fft_amd import lib
 
 def test_header_and_library_agree():
     hdr = open(os.path.join(H.ROOT, "include", "arm_fft_mi355.h")).read()
-    declared = set(re.findall(r"\b((?:arm_(?:cfft|rfft_fast|fft_mi355)|gnss|up_sample|iq_resamp)_[A-Za-z0-9_]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b((?:arm_(?:cfft|rfft_fast|rfft|fft_mi355)|gnss|up_sample|iq_resamp)_[A-Za-z0-9_]+)\s*\(", hdr))
     assert declared, "no declarations found"
     missing = [s for s in sorted(declared) if not hasattr(lib, s)]
     assert not missing, "declared but not exported: %s" % missing
@@ -129,6 +129,28 @@ def test_radix2_init_mirrors_reference_fields():
     S = R2()
     assert lib.arm_cfft_radix2_init_f32(ctypes.byref(S), 48, 1, 1) == fft_amd.ARM_MATH_ARGUMENT_ERROR
     assert S.fftLen == 48 and S.ifftFlag == 1 and S.bitReverseFlag == 1 and bool(S.pTwiddle)
+
+
+@pytest.mark.parametrize("kind", ["q15", "q31"])
+def test_rfft_fixed_init(kind):
+    """arm_rfft_init_q15.c:98-124: modifier 8192/N, realCoef tables = the oracle's, pCfft = the N/2-point instance"""
+    I = fft_amd.arm_rfft_instance_q15 if kind == "q15" else fft_amd.arm_rfft_instance_q31
+    assert ctypes.sizeof(I) == 40 and I.twidCoefRModifier.offset == 8 and I.pTwiddleAReal.offset == 16 and I.pCfft.offset == 32
+    dt, ct = (np.int16, H.c_i16) if kind == "q15" else (np.int32, H.c_i32)
+    wa, wb = np.zeros(8192, dt), np.zeros(8192, dt)
+    getattr(H.oracle(), "orc_real_coef_" + kind)(H.ptr(wa, ct), H.ptr(wb, ct))
+    for n in (32, 64, 128, 256, 512, 1024, 2048, 4096, 8192):
+        S = I()
+        assert getattr(lib, "arm_rfft_init_" + kind)(ctypes.byref(S), n, 1, 1) == 0
+        assert (S.fftLenReal, S.ifftFlagR, S.bitReverseFlagR, S.twidCoefRModifier, S.pCfft.contents.fftLen) == (n, 1, 1, 8192 // n, n // 2)
+        assert np.array_equal(np.ctypeslib.as_array(S.pTwiddleAReal, shape=(8192,)), wa)
+        assert np.array_equal(np.ctypeslib.as_array(S.pTwiddleBReal, shape=(8192,)), wb)
+        S2 = I()
+        assert getattr(lib, "arm_rfft_init_%d_%s" % (n, kind))(ctypes.byref(S2), 0, 1) == 0 and S2.fftLenReal == n and S2.ifftFlagR == 0
+    assert wa[0] == (16384 if kind == "q15" else 2 ** 30) and wa[1] == -wa[0] and wb[2 * 2048] == (32767 if kind == "q15" else 2 ** 31 - 1)
+    S = I()
+    for bad in (0, 16, 48, 16384, 65536):
+        assert getattr(lib, "arm_rfft_init_" + kind)(ctypes.byref(S), bad, 0, 1) == fft_amd.ARM_MATH_ARGUMENT_ERROR
 
 
 def test_u32_init():
