@@ -295,11 +295,29 @@ __global__ __launch_bounds__(GPlan<LOGN>::T) void gnss_code_spectrum_kernel(cons
 // ------------------------------------------------------------------------------------------
 // the fused acquisition kernel
 // ------------------------------------------------------------------------------------------
+// 2-bit I/Q samples of the fork's recordings, DecodeOrsIQCplx (CMSIS/CMSIS.cpp:465-485): one byte =
+// two complex samples, bits [1:0] I0, [3:2] Q0, [5:4] I1, [7:6] Q1, code -> {+1, -1, +3, -3}.  Decoding
+// inside the wipe-off load cuts the signal bytes 32x.
+__host__ __device__ __forceinline__ size_t ors_bytes(size_t n_samples) { return (n_samples + 1) / 2; }
+__device__ __forceinline__ float ors_level(unsigned code) { return (code & 2u ? 3.0f : 1.0f) * (code & 1u ? -1.0f : 1.0f); }
+__device__ __forceinline__ float2 ors_sample(const uint8_t *__restrict__ data, int n)
+{
+  const unsigned byte = data[n >> 1], sh = (n & 1) * 4;
+  return make_float2(ors_level((byte >> sh) & 3u), ors_level((byte >> (sh + 2)) & 3u));
+}
+
+__global__ void gnss_decode_ors_kernel(const uint8_t *__restrict__ data, uint32_t n_samples, float2 *__restrict__ out)
+{
+  const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n < n_samples) out[n] = ors_sample(data, (int)n);
+}
+
 constexpr int kMaxMs = 64;
 
 template <int LOGN>
 __global__ __launch_bounds__(GPlan<LOGN>::T, GPlan<LOGN>::T >= 1024 ? 4 : 3) void gnss_acquire_kernel(
-    const float2 *__restrict__ signal,   // [n_scenes][n_ms * spm]
+    const void *__restrict__ signal_any,  // [n_scenes][n_ms * spm] complex f32, or 2-bit packed (see ors_sample)
+    int packed,
     const float2 *__restrict__ spectra,  // [n_prn][N]
     const float2 *__restrict__ tw, const float *__restrict__ dopplers, const int32_t *__restrict__ prns, int n_prn, int n_dop,
     int dop_begin, int n_ms, int spm, int spc, int sep,
@@ -319,7 +337,8 @@ __global__ __launch_bounds__(GPlan<LOGN>::T, GPlan<LOGN>::T >= 1024 ? 4 : 3) voi
   const int d = dop_begin + blockIdx.x, scene = blockIdx.y;
   const double FS = 1.023e6 * (double)spc;
   const double fd = (double)dopplers[d];
-  const float2 *__restrict__ sig = signal + (size_t)scene * n_ms * spm;
+  const float2 *__restrict__ sig = reinterpret_cast<const float2 *>(signal_any) + (size_t)scene * n_ms * spm;
+  const uint8_t *__restrict__ ors = reinterpret_cast<const uint8_t *>(signal_any) + (size_t)scene * ors_bytes(n_ms * spm);
 
   if (tid < n_ms) {
     double cyc = fd * (double)tid * (double)spm / FS;
@@ -338,7 +357,7 @@ __global__ __launch_bounds__(GPlan<LOGN>::T, GPlan<LOGN>::T >= 1024 ? 4 : 3) voi
     if (e < spm) {
 #pragma unroll 2
       for (int b = 0; b < n_ms; b++) {
-        const float2 xv = sig[b * spm + e];
+        const float2 xv = packed ? ors_sample(ors, b * spm + e) : sig[b * spm + e];
         const float2 w = wblk[b];
         acc.x += xv.x * w.x - xv.y * w.y;
         acc.y += xv.x * w.y + xv.y * w.x;
@@ -437,7 +456,7 @@ hipError_t launch_spectrum(const gnss_acq_plan *pl, hipStream_t s)
 }
 
 template <int LOGN>
-hipError_t launch_acquire(const gnss_acq_plan *pl, const float2 *sig, uint32_t n_scenes, int d0, int d1, gnss_acq_result *all,
+hipError_t launch_acquire(const gnss_acq_plan *pl, const void *sig, int packed, uint32_t n_scenes, int d0, int d1, gnss_acq_result *all,
                           hipStream_t s)
 {
   using PL = GPlan<LOGN>;
@@ -445,7 +464,7 @@ hipError_t launch_acquire(const gnss_acq_plan *pl, const float2 *sig, uint32_t n
   auto k = gnss_acquire_kernel<LOGN>;
   hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  k<<<dim3(d1 - d0, n_scenes), PL::T, lds, s>>>(sig, pl->spectra_dev, pl->tw, pl->dops_dev, pl->prns_dev, pl->n_prn, pl->n_dop, d0,
+  k<<<dim3(d1 - d0, n_scenes), PL::T, lds, s>>>(sig, packed, pl->spectra_dev, pl->tw, pl->dops_dev, pl->prns_dev, pl->n_prn, pl->n_dop, d0,
                                                 pl->n_ms, pl->spm, pl->spc, pl->pk_sep, all);
   return hipGetLastError();
 }
@@ -539,20 +558,19 @@ arm_status gnss_acq_plan_set_peak_separation(gnss_acq_plan *pl, int32_t pk_sep)
 
 const float *gnss_acq_plan_code_spectra_dev(const gnss_acq_plan *pl) { return pl ? reinterpret_cast<const float *>(pl->spectra_dev) : nullptr; }
 
-arm_status gnss_acquire_dev(const gnss_acq_plan *pl, const float *signal_dev, uint32_t n_scenes, uint32_t dop_begin, uint32_t dop_end,
-                            gnss_acq_result *all_dev, gnss_acq_result *best_dev, void *stream)
+static arm_status acquire_any(const gnss_acq_plan *pl, const void *signal_dev, int packed, uint32_t n_scenes, uint32_t dop_begin,
+                              uint32_t dop_end, gnss_acq_result *all_dev, gnss_acq_result *best_dev, void *stream, const char *who)
 {
-  if (!pl || !signal_dev || !all_dev) { set_error("gnss_acquire_dev: null argument"); return ARM_MATH_ARGUMENT_ERROR; }
+  if (!pl || !signal_dev || !all_dev) { set_error("%s: null argument", who); return ARM_MATH_ARGUMENT_ERROR; }
   if (dop_begin > dop_end || dop_end > (uint32_t)pl->n_dop) {
-    set_error("gnss_acquire_dev: Doppler range [%u, %u) outside the plan's %d bins", dop_begin, dop_end, pl->n_dop);
+    set_error("%s: Doppler range [%u, %u) outside the plan's %d bins", who, dop_begin, dop_end, pl->n_dop);
     return ARM_MATH_ARGUMENT_ERROR;
   }
-  if (n_scenes > 65535) { set_error("gnss_acquire_dev: at most 65535 scenes per call"); return ARM_MATH_ARGUMENT_ERROR; }
+  if (n_scenes > 65535) { set_error("%s: at most 65535 scenes per call", who); return ARM_MATH_ARGUMENT_ERROR; }
   if (n_scenes == 0 || dop_begin == dop_end) return ARM_MATH_SUCCESS;
-  if (!plan_on_device(pl, "gnss_acquire_dev")) return ARM_MATH_ARGUMENT_ERROR;
+  if (!plan_on_device(pl, who)) return ARM_MATH_ARGUMENT_ERROR;
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = GNSS_DISPATCH(launch_acquire, pl->logn, pl, reinterpret_cast<const float2 *>(signal_dev), n_scenes, (int)dop_begin,
-                               (int)dop_end, all_dev, s);
+  hipError_t e = GNSS_DISPATCH(launch_acquire, pl->logn, pl, signal_dev, packed, n_scenes, (int)dop_begin, (int)dop_end, all_dev, s);
   if (!hip_ok(e, "gnss_acquire_kernel launch")) return ARM_MATH_ARGUMENT_ERROR;
   if (best_dev) {
     const int rows = (int)n_scenes * pl->n_prn;
@@ -560,6 +578,28 @@ arm_status gnss_acquire_dev(const gnss_acq_plan *pl, const float *signal_dev, ui
     if (!hip_ok(hipGetLastError(), "gnss_best_kernel launch")) return ARM_MATH_ARGUMENT_ERROR;
   }
   return ARM_MATH_SUCCESS;
+}
+
+arm_status gnss_acquire_dev(const gnss_acq_plan *pl, const float *signal_dev, uint32_t n_scenes, uint32_t dop_begin, uint32_t dop_end,
+                            gnss_acq_result *all_dev, gnss_acq_result *best_dev, void *stream)
+{
+  return acquire_any(pl, signal_dev, 0, n_scenes, dop_begin, dop_end, all_dev, best_dev, stream, "gnss_acquire_dev");
+}
+
+arm_status gnss_acquire_ors_dev(const gnss_acq_plan *pl, const uint8_t *ors_dev, uint32_t n_scenes, uint32_t dop_begin, uint32_t dop_end,
+                                gnss_acq_result *all_dev, gnss_acq_result *best_dev, void *stream)
+{
+  return acquire_any(pl, ors_dev, 1, n_scenes, dop_begin, dop_end, all_dev, best_dev, stream, "gnss_acquire_ors_dev");
+}
+
+arm_status gnss_decode_ors_iq_dev(const uint8_t *data_dev, uint32_t byte_length, float *iqs_dev, void *stream)
+{
+  if (!data_dev || !iqs_dev) { set_error("gnss_decode_ors_iq_dev: null argument"); return ARM_MATH_ARGUMENT_ERROR; }
+  if (byte_length == 0) return ARM_MATH_SUCCESS;
+  if (byte_length > 0x7FFFFFFFu) { set_error("gnss_decode_ors_iq_dev: at most 2^31-1 bytes per call"); return ARM_MATH_ARGUMENT_ERROR; }
+  const uint32_t n = 2 * byte_length;
+  gnss_decode_ors_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(data_dev, n, reinterpret_cast<float2 *>(iqs_dev));
+  return hip_ok(hipGetLastError(), "gnss_decode_ors_kernel launch") ? ARM_MATH_SUCCESS : ARM_MATH_ARGUMENT_ERROR;
 }
 
 arm_status gnss_acquire(gnss_acq_plan *pl, const float *signal, uint32_t n_scenes, gnss_acq_result *best, gnss_acq_result *all)

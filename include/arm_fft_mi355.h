@@ -311,6 +311,14 @@ const float32_t *gnss_acq_plan_code_spectra_dev(const gnss_acq_plan *plan);
  * on ties.  Asynchronous on `stream`, allocates nothing. */
 arm_status gnss_acquire_dev(const gnss_acq_plan *plan, const float32_t *signal_dev, uint32_t n_scenes, uint32_t dop_begin,
                             uint32_t dop_end, gnss_acq_result *all_dev, gnss_acq_result *best_dev, void *stream);
+/* same on the fork's 2-bit packed recordings: ors_dev = n_scenes x
+ * ceil(n_ms * samples_per_ms / 2) bytes, one byte = two complex samples decoded as DecodeOrsIQCplx does
+ * (CMSIS/CMSIS.cpp:465-485: bits [1:0] I0, [3:2] Q0, [5:4] I1, [7:6] Q1, code -> {+1, -1, +3, -3}); the
+ * decode happens inside the wipe-off load, the float signal never exists in memory. */
+arm_status gnss_acquire_ors_dev(const gnss_acq_plan *plan, const uint8_t *ors_dev, uint32_t n_scenes, uint32_t dop_begin,
+                                uint32_t dop_end, gnss_acq_result *all_dev, gnss_acq_result *best_dev, void *stream);
+/* DecodeOrsIQCplx itself (CMSIS/CMSIS.cpp:465-485) on device pointers: 2 * byte_length complex samples out */
+arm_status gnss_decode_ors_iq_dev(const uint8_t *data_dev, uint32_t byte_length, float32_t *iqs_dev, void *stream);
 /* host pointers, all bins; `all` may be NULL */
 arm_status gnss_acquire(gnss_acq_plan *plan, const float32_t *signal, uint32_t n_scenes, gnss_acq_result *best,
                         gnss_acq_result *all);

@@ -233,6 +233,19 @@ int orc_acquire_fused(const orc_c32 *signal, int n_ms, int spm, int fft_len, int
   return 0;
 }
 
+/* DecodeOrsIQCplx (CMSIS/CMSIS.cpp:465-485): 2-bit I/Q, two complex samples per byte */
+void orc_decode_ors_iq(const uint8_t *data, uint32_t byte_length, orc_c32 *iqs)
+{
+  static const int16_t tbl[4] = {1, -1, 3, -3};
+  for (uint32_t i = 0; i < byte_length; i++) {
+    uint8_t byte = data[i];
+    iqs[2 * i].r = (float)tbl[byte & 0x03];
+    iqs[2 * i].i = (float)tbl[(byte >> 2) & 0x03];
+    iqs[2 * i + 1].r = (float)tbl[(byte >> 4) & 0x03];
+    iqs[2 * i + 1].i = (float)tbl[(byte >> 6) & 0x03];
+  }
+}
+
 /* ---- resampler: iq_resamp_zp_* (up_sample.c:16-157) behind up_sample_N_to_M / up_sample_10k_to_16k
  * (gnss_codes.c:868-904) ---- */
 static double sinc_pi(double x) { return fabs(x) < 1e-12 ? 1.0 : sin(ORC_PI * x) / (ORC_PI * x); } /* up_sample.c:16-20 */

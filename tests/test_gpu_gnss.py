@@ -55,13 +55,20 @@ class Plan:
 
 
 def _same_cells(got, want, where=""):
-    """integer fields identical; peak/second 1e-4 relative; SNR 2e-3 dB; interpolated phase 2e-3 samples"""
+    """integer fields identical; peak/second 1e-4 relative; SNR 2e-3 dB; interpolated phase 2e-3 samples.
+    One exception, stated here: where the oracle's own two peaks are within 4e-6 of each other (a tie inside
+    f32 rounding of two different FFT implementations) the two indices may come out swapped."""
+    tie = (want["peak"] - want["second"]) <= 4e-6 * want["peak"]
+    swapped = tie & (got["code_phase"] == want["second_phase"]) & (got["second_phase"] == want["code_phase"])
+    assert swapped.sum() <= max(1, got.size // 1000), "too many rounding ties %s: %d" % (where, swapped.sum())
     for f in ("code_phase", "second_phase", "doppler_bin", "prn"):
-        assert np.array_equal(got[f], want[f]), "%s differs %s: %s" % (f, where, np.argwhere(got[f] != want[f])[:5])
+        bad = (got[f] != want[f]) & ~swapped
+        assert not bad.any(), "%s differs %s: %s" % (f, where, np.argwhere(bad)[:5])
     assert np.allclose(got["peak"], want["peak"], rtol=1e-4, atol=0)
     assert np.allclose(got["second"], want["second"], rtol=1e-4, atol=0)
-    assert np.abs(got["snr_db"] - want["snr_db"]).max() <= 2e-3
-    assert np.abs(got["code_phase_interp"] - want["code_phase_interp"]).max() <= 2e-3
+    ok = ~swapped
+    assert np.abs(got["snr_db"] - want["snr_db"])[ok].max() <= 2e-3
+    assert np.abs(got["code_phase_interp"] - want["code_phase_interp"])[ok].max() <= 2e-3
 
 
 # ------------------------------------------------------------------ a10: getCode
@@ -270,3 +277,59 @@ def test_plan_argument_errors():
     assert lib.gnss_acquire_dev(p, ctypes.c_void_p(sig.data_ptr()), 0, 0, 1, ctypes.c_void_p(out.data_ptr()), None, None) == 0
     lib.gnss_acq_plan_destroy(p)
     lib.gnss_acq_plan_destroy(None)
+
+
+# ------------------------------------------------------------------ 8(f).3: 2-bit packed recordings
+def _quantise_ors(sig):
+    """complex f32 samples -> the fork's 2-bit bytes (code 0:+1 1:-1 2:+3 3:-3, I0 | Q0<<2 | I1<<4 | Q1<<6)"""
+    x = np.asarray(sig, np.float32).reshape(-1, 2)
+    thr = 2.0 * np.median(np.abs(x))
+    code = (np.abs(x) > thr).astype(np.uint8) * 2 + (x < 0).astype(np.uint8)
+    if code.shape[0] % 2:
+        code = np.vstack([code, np.zeros((1, 2), np.uint8)])
+    c = code.reshape(-1, 2, 2)
+    return (c[:, 0, 0] | (c[:, 0, 1] << 2) | (c[:, 1, 0] << 4) | (c[:, 1, 1] << 6)).astype(np.uint8)
+
+
+def test_decode_ors_iq_dev_identical_to_oracle():
+    import torch
+    import gpu_util as G
+    fa, lib = _lib()
+    data = np.concatenate([np.arange(256, dtype=np.uint8), H.rng(42).integers(0, 256, 5001).astype(np.uint8)])
+    want = np.zeros((2 * data.size, 2), np.float32)
+    H.oracle().orc_decode_ors_iq(data.ctypes.data_as(ctypes.c_void_p), data.size, want.ctypes.data_as(ctypes.c_void_p))
+    d = _dev(data)
+    out = torch.zeros((2 * data.size, 2), dtype=torch.float32, device="cuda")
+    G.check(lib.gnss_decode_ors_iq_dev(ctypes.c_void_p(d.data_ptr()), data.size, ctypes.c_void_p(out.data_ptr()), G.stream_ptr()))
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), want)
+    assert set(np.unique(want)) == {-3.0, -1.0, 1.0, 3.0}
+
+
+def test_acquisition_on_packed_recordings_equals_decoded_float_path():
+    """gnss_acquire_ors_dev decodes inside the wipe-off load: tuples bit-identical to decoding first
+    (DecodeOrsIQCplx) and running the float path; both identical to the oracle in the integer fields."""
+    import torch
+    import gpu_util as G
+    fa, lib = _lib()
+    scenes = [H.make_gps_scene(seed=21), H.make_gps_scene(seed=22, offset_hz=40.0)]
+    packed = np.stack([_quantise_ors(s) for s in scenes])                 # [2, 20460] bytes
+    decoded = np.zeros((2, 40920, 2), np.float32)
+    for i in range(2):
+        H.oracle().orc_decode_ors_iq(packed[i].ctypes.data_as(ctypes.c_void_p), packed.shape[1], decoded[i].ctypes.data_as(ctypes.c_void_p))
+    pl = Plan(4096, 4092, 10, 4, H.ALL_PRNS, H.DOPPLER_GRID)
+    fbest, fall = pl.acquire_dev(decoded)
+    d = _dev(packed)
+    allc = torch.zeros((2, 32, 41, 8), dtype=torch.int32, device="cuda")
+    best = torch.zeros((2, 32, 8), dtype=torch.int32, device="cuda")
+    G.check(lib.gnss_acquire_ors_dev(pl.p, ctypes.c_void_p(d.data_ptr()), 2, 0, 41, ctypes.c_void_p(allc.data_ptr()),
+                                     ctypes.c_void_p(best.data_ptr()), G.stream_ptr()))
+    torch.cuda.synchronize()
+    assert allc.cpu().numpy().tobytes() == fall.view(np.int32).tobytes() and best.cpu().numpy().tobytes() == fbest.view(np.int32).tobytes()
+    for i in range(2):
+        wb, wa = H.oracle_acquire(decoded[i], 10, 4092, 4096, 4, H.ALL_PRNS, H.DOPPLER_GRID)
+        _same_cells(fall[i], wa, "packed scene %d" % i)
+    for prn, ph, fd in zip(H.GPS_SCENE["prns"], H.GPS_SCENE["phases"], H.GPS_SCENE["dopplers"]):
+        b = fbest[0][prn - 1]                                             # 2-bit quantisation keeps the scene detectable
+        assert H.DOPPLER_GRID[b["doppler_bin"]] == fd and ph <= b["code_phase"] <= ph + 4
+    pl.close()
