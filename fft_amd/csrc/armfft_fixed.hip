@@ -46,83 +46,71 @@ __device__ __forceinline__ int32_t mulhi32(int32_t a, int32_t b) { return __mulh
 // i0, i0+n2, i0+2n2, i0+3n2; w1/w2/w3 the twiddles at ic, 2ic, 3ic.  Outputs go back in place:
 // x[1] receives the "c" output (twiddle 2), x[2] the "b" output (twiddle 1), x[3] "d" (twiddle 3).
 // ------------------------------------------------------------------------------------------
-template <int STAGE, bool INV>
-__device__ __forceinline__ void bfly_q15(Q15::cpx *x, Q15::cpx w1, Q15::cpx w2, Q15::cpx w3)
+// Packed form: one complex point = one 32-bit register {re, im}; saturating adds are
+// v_pk_add_i16/v_pk_sub_i16 with clamp (= __SSAT(a +- b, 16)), halvings v_pk_ashrrev_i16, the
+// x -+ j*y cross terms a packed add and a packed sub of the half-swapped operand blended per half,
+// and the first product of every complex multiply one v_dot2_i32_i16.  Every intermediate has the
+// value the reference's scalar code gives it (sums of two halved q15 values fit 16 bits; the dot
+// product |co*a + si*b| <= sqrt(2) * 2^30 fits 32 bits).
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s16x2 to_v(Q15::cpx c) { return __builtin_bit_cast(s16x2, c); }
+__device__ __forceinline__ Q15::cpx to_c(s16x2 v) { return __builtin_bit_cast(Q15::cpx, v); }
+__device__ __forceinline__ s16x2 sat_add(s16x2 a, s16x2 b) { return __builtin_elementwise_add_sat(a, b); }
+__device__ __forceinline__ s16x2 sat_sub(s16x2 a, s16x2 b) { return __builtin_elementwise_sub_sat(a, b); }
+__device__ __forceinline__ s16x2 half(s16x2 a) { return a >> (short)1; }
+__device__ __forceinline__ s16x2 swap_ri(s16x2 a) { return __builtin_shufflevector(a, a, 1, 0); }
+__device__ __forceinline__ s16x2 lo_hi(s16x2 lo, s16x2 hi) { return __builtin_shufflevector(lo, hi, 0, 3); }  // {lo.x, hi.y}
+// forward: (co*x.re + si*x.im, co*x.im - si*x.re) >> 16;  inverse: (co*x.re - si*x.im, co*x.im + si*x.re) >> 16
+template <bool INV>
+__device__ __forceinline__ s16x2 cmul_q15(s16x2 x, s16x2 w)
 {
-  int16_t R0, R1, S0, S1, T0, T1, U0, U1, out1, out2;
-  const int16_t Co1 = w1.re, Si1 = w1.im, Co2 = w2.re, Si2 = w2.im, Co3 = w3.re, Si3 = w3.im;
+  const int co = w.x, si = w.y, xr = x.x, xi = x.y;
+  int re, im;
+  if (!INV) {
+    re = __builtin_amdgcn_sdot2(w, x, 0, false);
+    im = co * xi - si * xr;
+  } else {
+    re = co * xr - si * xi;
+    im = __builtin_amdgcn_sdot2(w, swap_ri(x), 0, false);  // co*x.im + si*x.re
+  }
+  s16x2 r;
+  r.x = (short)(re >> 16);
+  r.y = (short)(im >> 16);
+  return r;
+}
+
+template <int STAGE, bool INV>
+__device__ __forceinline__ void bfly_q15(Q15::cpx *x, Q15::cpx w1c, Q15::cpx w2c, Q15::cpx w3c)
+{
+  const s16x2 w1 = to_v(w1c), w2 = to_v(w2c), w3 = to_v(w3c);
+  s16x2 x0 = to_v(x[0]), x1 = to_v(x[1]), x2 = to_v(x[2]), x3 = to_v(x[3]);
+  if (STAGE == 0) {  // guard bits of the first stage (arm_cfft_radix4_q15.c:626-640)
+    x0 = x0 >> (short)2; x1 = x1 >> (short)2; x2 = x2 >> (short)2; x3 = x3 >> (short)2;
+  }
+  s16x2 R = sat_add(x0, x2), S = sat_sub(x0, x2);
+  s16x2 T = sat_add(x1, x3);
+  s16x2 o0 = half(R) + half(T);
+  if (STAGE == 1) o0 = half(o0);
+  R = (STAGE == 0) ? sat_sub(R, T) : (half(R) - half(T));
+  const s16x2 o1 = (STAGE == 2) ? R : cmul_q15<INV>(R, w2);
+  T = sat_sub(x1, x3);
+  // forward: R' = S - j*T... in components (S.re - T.im, S.im + T.re) and S' = (S.re + T.im, S.im - T.re); inverse swaps them
+  s16x2 diff, sum;
   if (STAGE == 0) {
-    T0 = x[0].re >> 2; T1 = x[0].im >> 2;
-    S0 = x[2].re >> 2; S1 = x[2].im >> 2;
+    const s16x2 Ts = swap_ri(T);
+    diff = sat_sub(S, Ts);
+    sum = sat_add(S, Ts);
   } else {
-    T0 = x[0].re; T1 = x[0].im;
-    S0 = x[2].re; S1 = x[2].im;
+    const s16x2 Sh = half(S), Th = swap_ri(half(T));
+    diff = Sh - Th;
+    sum = Sh + Th;
   }
-  R0 = (int16_t)ssat16(T0 + S0); R1 = (int16_t)ssat16(T1 + S1);
-  S0 = (int16_t)ssat16(T0 - S0); S1 = (int16_t)ssat16(T1 - S1);
-  int16_t B0, B1, D0, D1;  // the (scaled) inputs at i1 and i3
-  if (STAGE == 0) {
-    B0 = x[1].re >> 2; B1 = x[1].im >> 2;
-    D0 = x[3].re >> 2; D1 = x[3].im >> 2;
-  } else {
-    B0 = x[1].re; B1 = x[1].im;
-    D0 = x[3].re; D1 = x[3].im;
-  }
-  T0 = (int16_t)ssat16(B0 + D0); T1 = (int16_t)ssat16(B1 + D1);
-  if (STAGE == 1) {
-    x[0].re = (int16_t)(((R0 >> 1) + (T0 >> 1)) >> 1);
-    x[0].im = (int16_t)(((R1 >> 1) + (T1 >> 1)) >> 1);
-  } else {
-    x[0].re = (int16_t)((R0 >> 1) + (T0 >> 1));
-    x[0].im = (int16_t)((R1 >> 1) + (T1 >> 1));
-  }
-  if (STAGE == 0) {
-    R0 = (int16_t)ssat16(R0 - T0); R1 = (int16_t)ssat16(R1 - T1);
-  } else {
-    R0 = (int16_t)((R0 >> 1) - (T0 >> 1)); R1 = (int16_t)((R1 >> 1) - (T1 >> 1));
-  }
-  if (STAGE == 2) {
-    out1 = R0; out2 = R1;
-  } else if (!INV) {
-    out1 = (int16_t)((Co2 * R0 + Si2 * R1) >> 16);
-    out2 = (int16_t)((-Si2 * R0 + Co2 * R1) >> 16);
-  } else {
-    out1 = (int16_t)((Co2 * R0 - Si2 * R1) >> 16);
-    out2 = (int16_t)((Si2 * R0 + Co2 * R1) >> 16);
-  }
-  x[1].re = out1; x[1].im = out2;
-  T0 = (int16_t)ssat16(B0 - D0); T1 = (int16_t)ssat16(B1 - D1);
-  if (STAGE == 0) {
-    if (!INV) {
-      R0 = (int16_t)ssat16((int)S0 - T1); R1 = (int16_t)ssat16((int)S1 + T0);
-      S0 = (int16_t)ssat16((int)S0 + T1); S1 = (int16_t)ssat16((int)S1 - T0);
-    } else {
-      R0 = (int16_t)ssat16((int)S0 + T1); R1 = (int16_t)ssat16((int)S1 - T0);
-      S0 = (int16_t)ssat16((int)S0 - T1); S1 = (int16_t)ssat16((int)S1 + T0);
-    }
-  } else {
-    if (!INV) {
-      R0 = (int16_t)((S0 >> 1) - (T1 >> 1)); R1 = (int16_t)((S1 >> 1) + (T0 >> 1));
-      S0 = (int16_t)((S0 >> 1) + (T1 >> 1)); S1 = (int16_t)((S1 >> 1) - (T0 >> 1));
-    } else {
-      R0 = (int16_t)((S0 >> 1) + (T1 >> 1)); R1 = (int16_t)((S1 >> 1) - (T0 >> 1));
-      S0 = (int16_t)((S0 >> 1) - (T1 >> 1)); S1 = (int16_t)((S1 >> 1) + (T0 >> 1));
-    }
-  }
-  if (STAGE == 2) {
-    x[2].re = S0; x[2].im = S1;
-    x[3].re = R0; x[3].im = R1;
-  } else if (!INV) {
-    x[2].re = (int16_t)((Co1 * S0 + Si1 * S1) >> 16);
-    x[2].im = (int16_t)((-Si1 * S0 + Co1 * S1) >> 16);
-    x[3].re = (int16_t)((Si3 * R1 + Co3 * R0) >> 16);
-    x[3].im = (int16_t)((-Si3 * R0 + Co3 * R1) >> 16);
-  } else {
-    x[2].re = (int16_t)((Co1 * S0 - Si1 * S1) >> 16);
-    x[2].im = (int16_t)((Si1 * S0 + Co1 * S1) >> 16);
-    x[3].re = (int16_t)((Co3 * R0 - Si3 * R1) >> 16);
-    x[3].im = (int16_t)((Si3 * R0 + Co3 * R1) >> 16);
-  }
+  const s16x2 Rn = INV ? lo_hi(sum, diff) : lo_hi(diff, sum);
+  const s16x2 Sn = INV ? lo_hi(diff, sum) : lo_hi(sum, diff);
+  x[0] = to_c(o0);
+  x[1] = to_c(o1);
+  x[2] = to_c((STAGE == 2) ? Sn : cmul_q15<INV>(Sn, w1));
+  x[3] = to_c((STAGE == 2) ? Rn : cmul_q15<INV>(Rn, w3));
 }
 
 // radix-2 pre-stage of arm_cfft_radix4by2[_inverse]_q15 (arm_cfft_q15.c:786-804, :885-903)
@@ -298,8 +286,8 @@ struct StageKind { static constexpr int value = (S == 0) ? 0 : ((S == M - 1) ? 2
 // (S, S+1) or one.  r = group index inside the sub-transform (0 .. L/16-1), base = first point of
 // the sub-transform in LDS, tw = table of the FULL transform (3N/4 entries), TWMOD0 = 1 or 2
 // (arm_cfft_radix4by2 calls the butterflies with twidCoefModifier 2).
-template <class Q, int LOGL, int S, bool PAIR, bool INV, int TWMOD0>
-__device__ __forceinline__ void fused_step(typename Q::word *lds, const typename Q::tword *__restrict__ tw, int base, int r)
+template <class Q, int LOGL, int S, bool PAIR, bool INV, int TWMOD0, class TWP>
+__device__ __forceinline__ void fused_step(typename Q::word *lds, TWP tw, int base, int r)
 {
   using cpx = typename Q::cpx;
   constexpr int M = LOGL / 2;
@@ -366,8 +354,8 @@ __device__ __forceinline__ void fused_step(typename Q::word *lds, const typename
 }
 
 // all radix-4 stages from S on: a single stage first when the count is odd, then pairs
-template <class Q, int LOGL, int S, bool INV, int TWMOD0>
-__device__ __forceinline__ void run_stages(typename Q::word *lds, const typename Q::tword *__restrict__ tw, int base, int r)
+template <class Q, int LOGL, int S, bool INV, int TWMOD0, class TWP>
+__device__ __forceinline__ void run_stages(typename Q::word *lds, TWP tw, int base, int r)
 {
   constexpr int M = LOGL / 2;
   if constexpr (S < M) {
@@ -378,19 +366,15 @@ __device__ __forceinline__ void run_stages(typename Q::word *lds, const typename
   }
 }
 
-template <class Q, int LOGN, bool INV>
-__global__ __launch_bounds__(FixedPlan<LOGN>::T, 4) void cfft_fixed_kernel(typename Q::word *__restrict__ data,
-                                                                          const typename Q::tword *__restrict__ tw, uint32_t batch,
-                                                                          uint32_t ngroups, int bitrev)
+// One group of TPB transforms: global -> LDS, all stages, LDS -> global.  TWP = pointer to the twiddle
+// table, in global memory or (persistent variant) in LDS.
+template <class Q, int LOGN, bool INV, class TWP>
+__device__ __forceinline__ void fixed_one_group(typename Q::word *__restrict__ data, TWP tw, typename Q::word *lds, uint32_t batch,
+                                                uint32_t g, int bitrev, int tid)
 {
   using PL = FixedPlan<LOGN>;
   using word = typename Q::word;
   using cpx = typename Q::cpx;
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  word *lds = reinterpret_cast<word *>(lds_raw);
-  const int tid = threadIdx.x;
-  const uint32_t g = blockIdx.x + blockIdx.y * gridDim.x;
-  if (g >= ngroups) return;
   const size_t gbase = (size_t)g * PL::ELEMS;  // first point of this workgroup's transforms
   const uint32_t nvalid = (batch - g * PL::TPB) >= (uint32_t)PL::TPB ? (uint32_t)PL::ELEMS : (batch - g * PL::TPB) * PL::N;
 
@@ -449,6 +433,40 @@ __global__ __launch_bounds__(FixedPlan<LOGN>::T, 4) void cfft_fixed_kernel(typen
   }
 }
 
+// Persistent variant for the sizes where it pays (FixedTune): the 3N/4-entry twiddle table is copied to
+// LDS once per workgroup and the workgroup loops over groups of transforms.  The per-butterfly twiddle
+// reads are gathers (every lane its own entry): from global memory each costs one L1 line per lane.
+template <class Q, int LOGN> struct FixedTune { static constexpr int WGPCU = 0; };
+template <> struct FixedTune<Q15, 12> { static constexpr int WGPCU = 5; };
+
+template <class Q, int LOGN, bool INV>
+__global__ __launch_bounds__(FixedPlan<LOGN>::T, 4) void cfft_fixed_kernel(typename Q::word *__restrict__ data,
+                                                                          const typename Q::tword *__restrict__ tw, uint32_t batch,
+                                                                          uint32_t ngroups, int bitrev)
+{
+  using PL = FixedPlan<LOGN>;
+  using word = typename Q::word;
+  using tword = typename Q::tword;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  word *lds = reinterpret_cast<word *>(lds_raw);
+  const uint32_t g0 = blockIdx.x + blockIdx.y * gridDim.x;
+  if (g0 >= ngroups) return;
+  if constexpr (FixedTune<Q, LOGN>::WGPCU > 0) {
+    tword *tl = reinterpret_cast<tword *>(lds + PL::LDS_WORDS);
+    for (int i = threadIdx.x; i < 3 * PL::N / 4; i += PL::T) tl[i] = tw[i];
+    __syncthreads();
+    const uint32_t gstep = gridDim.x * gridDim.y;
+    for (uint32_t g = g0; g < ngroups; g += gstep) {
+      int tid = threadIdx.x;
+      asm volatile("" : "+v"(tid));  // keep the per-thread address math inside the loop
+      fixed_one_group<Q, LOGN, INV>(data, (const tword *)tl, lds, batch, g, bitrev, tid);
+      __syncthreads();
+    }
+  } else {
+    fixed_one_group<Q, LOGN, INV>(data, tw, lds, batch, g0, bitrev, threadIdx.x);
+  }
+}
+
 // ---- twiddle generation on the device (checked against the host table by the caller) ----
 template <typename T>
 __global__ void gen_twiddle_fixed_kernel(T *tw, uint32_t n, int rounding)
@@ -490,7 +508,8 @@ template <class Q, int LOGN, bool INV>
 static hipError_t launch_fixed_one(typename Q::word *data, const typename Q::tword *tw, uint32_t batch, bool bitrev, hipStream_t stream)
 {
   using PL = FixedPlan<LOGN>;
-  constexpr size_t lds_bytes = (size_t)PL::LDS_WORDS * sizeof(typename Q::word);
+  constexpr int WGPCU = FixedTune<Q, LOGN>::WGPCU;
+  constexpr size_t lds_bytes = (size_t)PL::LDS_WORDS * sizeof(typename Q::word) + (WGPCU ? (size_t)(3 * PL::N / 4) * sizeof(typename Q::tword) : 0);
   static bool attr_done[16] = {false};
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -501,8 +520,14 @@ static hipError_t launch_fixed_one(typename Q::word *data, const typename Q::two
     attr_done[dev] = true;
   }
   const uint32_t ngroups = (batch + PL::TPB - 1) / PL::TPB;
-  const uint32_t gx = ngroups < 65536u ? ngroups : 65536u;
-  kern<<<dim3(gx, (ngroups + gx - 1) / gx, 1), PL::T, lds_bytes, stream>>>(data, tw, batch, ngroups, bitrev ? 1 : 0);
+  uint32_t gx = ngroups < 65536u ? ngroups : 65536u, gy = (ngroups + gx - 1) / gx;
+  if (WGPCU) {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    const uint32_t resident = (uint32_t)(WGPCU * cus);
+    if (ngroups > resident) { gx = resident; gy = 1; }
+  }
+  kern<<<dim3(gx, gy, 1), PL::T, lds_bytes, stream>>>(data, tw, batch, ngroups, bitrev ? 1 : 0);
   return hipGetLastError();
 }
 
