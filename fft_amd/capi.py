@@ -86,7 +86,7 @@ EXPORTED_SYMBOLS = (
     + ["arm_cfft_radix2_init_f32", "arm_cfft_radix2_f32", "arm_cfft_radix2_batch_f32", "arm_cfft_radix2_f32_dev"]
     + ["arm_cfft_init_u32_f32", "arm_cfft_u32_f32_dev", "arm_cfft_u32_batch_f32"]
     + ["gnss_acq_plan_create", "gnss_acq_plan_destroy", "gnss_acq_plan_set_peak_separation", "gnss_acq_plan_code_spectra_dev",
-       "gnss_acquire_dev", "gnss_acquire_ors_dev", "gnss_decode_ors_iq_dev", "gnss_acquire", "gnss_get_code_dev", "gnss_synth_gps_prn_dev", "gnss_find_top2_peaks_dev"]
+       "gnss_acquire_dev", "gnss_acquire_ors_dev", "gnss_decode_ors_iq_dev", "gnss_acq_workspace_bytes", "gnss_acquire_groups_dev", "gnss_acquire", "gnss_get_code_dev", "gnss_synth_gps_prn_dev", "gnss_find_top2_peaks_dev"]
     + ["arm_rfft_init_q15", "arm_rfft_init_q31", "arm_rfft_q15", "arm_rfft_q31", "arm_rfft_batch_q15", "arm_rfft_batch_q31",
        "arm_rfft_q15_dev", "arm_rfft_q31_dev"]
     + ["arm_rfft_init_%d_%s" % (n, q) for n in (32, 64, 128, 256, 512, 1024, 2048, 4096, 8192) for q in ("q15", "q31")]
@@ -154,6 +154,9 @@ def _load():
     L.gnss_acquire_dev.argtypes, L.gnss_acquire_dev.restype = [c_void_p, c_void_p, u32, u32, u32, c_void_p, c_void_p, c_void_p], c_int
     L.gnss_acquire_ors_dev.argtypes, L.gnss_acquire_ors_dev.restype = [c_void_p, c_void_p, u32, u32, u32, c_void_p, c_void_p, c_void_p], c_int
     L.gnss_decode_ors_iq_dev.argtypes, L.gnss_decode_ors_iq_dev.restype = [c_void_p, u32, c_void_p, c_void_p], c_int
+    L.gnss_acq_workspace_bytes.argtypes, L.gnss_acq_workspace_bytes.restype = [c_void_p, u32, u32, u32], ctypes.c_size_t
+    L.gnss_acquire_groups_dev.argtypes = [c_void_p, c_void_p, u32, u32, u32, i32, u32, c_void_p, c_void_p, c_void_p, c_void_p]
+    L.gnss_acquire_groups_dev.restype = c_int
     L.gnss_acquire.argtypes, L.gnss_acquire.restype = [c_void_p, c_void_p, u32, c_void_p, c_void_p], c_int
     L.gnss_get_code_dev.argtypes, L.gnss_get_code_dev.restype = [i32, i32, i32, c_void_p], c_int
     L.gnss_synth_gps_prn_dev.argtypes, L.gnss_synth_gps_prn_dev.restype = [i32, c_float, u32, c_void_p, i32], c_int

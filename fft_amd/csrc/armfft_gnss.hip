@@ -312,6 +312,53 @@ __global__ void gnss_decode_ors_kernel(const uint8_t *__restrict__ data, uint32_
   if (n < n_samples) out[n] = ors_sample(data, (int)n);
 }
 
+// Wipe-off + coherent fold of milliseconds [ms0, ms0 + count) + forward FFT; on return (after the
+// trailing barrier) lds[PL::idx(0, k)] holds the spectrum in natural order.  The carrier phase is
+// referenced to sample 0 of the scene, so groups of milliseconds stay phase-continuous.
+template <class PL>
+__device__ __forceinline__ void fold_and_fft(float2 *lds, float2 *wblk, const float2 *__restrict__ tw, const float2 *__restrict__ sig,
+                                             const uint8_t *__restrict__ ors, int packed, double fd, double FS, int ms0, int count, int spm,
+                                             int tid)
+{
+  constexpr int N = PL::N, T = PL::T;
+  if (tid < count) {
+    double cyc = fd * (double)(ms0 + tid) * (double)spm / FS;
+    cyc -= floor(cyc);
+    double s, c;
+    sincospi(2.0 * cyc, &s, &c);
+    wblk[tid] = make_float2((float)c, (float)(-s));
+  }
+  __syncthreads();
+  // one point at a time: the double-precision phase is register-hungry
+#pragma unroll 1
+  for (int e = tid; e < N; e += T) {
+    float2 acc = make_float2(0.f, 0.f);
+    if (e < spm) {
+#pragma unroll 2
+      for (int b = 0; b < count; b++) {
+        const int n = (ms0 + b) * spm + e;
+        const float2 xv = packed ? ors_sample(ors, n) : sig[n];
+        const float2 w = wblk[b];
+        acc.x += xv.x * w.x - xv.y * w.y;
+        acc.y += xv.x * w.y + xv.y * w.x;
+      }
+      double cyc = fd * (double)e / FS;
+      cyc -= floor(cyc);
+      double s, c;
+      sincospi(2.0 * cyc, &s, &c);
+      acc = cmul(acc, make_float2((float)c, (float)(-s)));
+    }
+    lds[PL::idx(0, e)] = acc;
+  }
+  __syncthreads();
+  {
+    auto ld = [&](int, int e) -> float2 { return lds[PL::idx(0, e)]; };
+    auto st = [&](int, int k, float2 v) { lds[PL::idx(0, k)] = v; };
+    fft_block<PL, true, true>(lds, tw, tid, ld, st);
+  }
+  __syncthreads();
+}
+
 constexpr int kMaxMs = 64;
 
 template <int LOGN>
@@ -340,43 +387,7 @@ __global__ __launch_bounds__(GPlan<LOGN>::T, GPlan<LOGN>::T >= 1024 ? 4 : 3) voi
   const float2 *__restrict__ sig = reinterpret_cast<const float2 *>(signal_any) + (size_t)scene * n_ms * spm;
   const uint8_t *__restrict__ ors = reinterpret_cast<const uint8_t *>(signal_any) + (size_t)scene * ors_bytes(n_ms * spm);
 
-  if (tid < n_ms) {
-    double cyc = fd * (double)tid * (double)spm / FS;
-    cyc -= floor(cyc);
-    double s, c;
-    sincospi(2.0 * cyc, &s, &c);
-    wblk[tid] = make_float2((float)c, (float)(-s));
-  }
-  __syncthreads();
-
-  // ---- wipe-off + coherent fold into LDS (one point at a time: the double-precision phase is
-  //      register-hungry), then the forward FFT, spectrum back to LDS in natural order ----
-#pragma unroll 1
-  for (int e = tid; e < N; e += T) {
-    float2 acc = make_float2(0.f, 0.f);
-    if (e < spm) {
-#pragma unroll 2
-      for (int b = 0; b < n_ms; b++) {
-        const float2 xv = packed ? ors_sample(ors, b * spm + e) : sig[b * spm + e];
-        const float2 w = wblk[b];
-        acc.x += xv.x * w.x - xv.y * w.y;
-        acc.y += xv.x * w.y + xv.y * w.x;
-      }
-      double cyc = fd * (double)e / FS;
-      cyc -= floor(cyc);
-      double s, c;
-      sincospi(2.0 * cyc, &s, &c);
-      acc = cmul(acc, make_float2((float)c, (float)(-s)));
-    }
-    lds[PL::idx(0, e)] = acc;
-  }
-  __syncthreads();
-  {
-    auto ld = [&](int, int e) -> float2 { return lds[PL::idx(0, e)]; };
-    auto st = [&](int, int k, float2 v) { lds[PL::idx(0, k)] = v; };
-    fft_block<PL, true, true>(lds, tw, tid, ld, st);
-  }
-  __syncthreads();
+  fold_and_fft<PL>(lds, wblk, tw, sig, ors, packed, fd, FS, 0, n_ms, spm, tid);
   // conj(Z) in the order the first pass consumes its inputs
   float2 zc[16];
   for_each_first_pass_input<PL>(tid, [&](int slot, int, int e) {
@@ -404,6 +415,96 @@ __global__ __launch_bounds__(GPlan<LOGN>::T, GPlan<LOGN>::T >= 1024 ? 4 : 3) voi
     const Top2 t = top2_scan<T, 16, true>(mag, N, sep, lt, xch);
     if (lt == 0) finish_row(t, mag, N, d, prns[p], all + ((size_t)scene * n_prn + p) * n_dop + d);
     __syncthreads();  // the row is dead: the next IFFT may overwrite it
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// non-coherent and differential accumulation over groups of milliseconds
+// ------------------------------------------------------------------------------------------
+// The n_ms milliseconds of a scene are cut into n_groups groups; every group is folded coherently and
+// correlated on its own, y_g = IFFT(FFT(z_g) conj(C_p)), and the rows are combined as
+//   MODE 1 (non-coherent, the NCI loop of CMSIS/CMSIS.cpp:915-943):   r[m] = sum_g |y_g[m]|
+//   MODE 2 (differential, test_quasi_diff_pilot CMSIS.cpp:1030-1062): r[m] = |sum_{g>=1} y_g[m] conj(y_{g-1}[m])|
+// followed by find_top2_peaks_real / compute_snr_real / InterpolateCodePhase on r (CMSIS.cpp:948-951).
+// Two kernels: the group spectra (conjugated) go through a caller-provided workspace, because one
+// workgroup cannot hold n_groups spectra (32 KiB each at 4096 points) next to its FFT image.
+template <int LOGN>
+__global__ __launch_bounds__(GPlan<LOGN>::T, 4) void gnss_group_spectra_kernel(const void *__restrict__ signal_any, int packed,
+                                                                              const float2 *__restrict__ tw, const float *__restrict__ dopplers,
+                                                                              int dop_begin, int n_ms, int ms_per_group, int spm, int spc,
+                                                                              float2 *__restrict__ work)  // [scene][d_local][group][N]
+{
+  using PL = GPlan<LOGN>;
+  constexpr int N = PL::N, T = PL::T;
+  extern __shared__ __attribute__((aligned(16))) float2 lds[];
+  float2 *wblk = lds + PL::LDS_ELEMS;
+  const int tid = threadIdx.x, g = blockIdx.z, scene = blockIdx.y, n_groups = gridDim.z;
+  const double FS = 1.023e6 * (double)spc, fd = (double)dopplers[dop_begin + blockIdx.x];
+  const float2 *__restrict__ sig = reinterpret_cast<const float2 *>(signal_any) + (size_t)scene * n_ms * spm;
+  const uint8_t *__restrict__ ors = reinterpret_cast<const uint8_t *>(signal_any) + (size_t)scene * ors_bytes(n_ms * spm);
+  fold_and_fft<PL>(lds, wblk, tw, sig, ors, packed, fd, FS, g * ms_per_group, ms_per_group, spm, tid);
+  float2 *__restrict__ dst = work + (((size_t)scene * gridDim.x + blockIdx.x) * n_groups + g) * N;
+  for (int k = tid; k < N; k += T) {
+    const float2 z = lds[PL::idx(0, k)];
+    dst[k] = make_float2(z.x, -z.y);
+  }
+}
+
+template <int LOGN, int MODE>
+__global__ __launch_bounds__(GPlan<LOGN>::T, GPlan<LOGN>::T >= 1024 ? 4 : 2) void gnss_accumulate_kernel(
+    const float2 *__restrict__ work, const float2 *__restrict__ spectra, const float2 *__restrict__ tw, const int32_t *__restrict__ prns,
+    int n_prn, int n_dop, int dop_begin, int n_groups, int sep, gnss_acq_result *__restrict__ all)
+{
+  using PL = GPlan<LOGN>;
+  constexpr int N = PL::N, T = PL::T;
+  extern __shared__ __attribute__((aligned(16))) float2 lds[];
+  unsigned char *xch = reinterpret_cast<unsigned char *>(lds + PL::LDS_ELEMS);
+  float *magl = reinterpret_cast<float *>(lds);
+  auto mag_idx = [](int m) { return m + ((m >> 4) << 2); };
+  const int tid = threadIdx.x, d = dop_begin + blockIdx.x, scene = blockIdx.y;
+  const float2 *__restrict__ zbase = work + ((size_t)scene * gridDim.x + blockIdx.x) * n_groups * N;
+  const float inv_n = 1.0f / (float)N;
+  const int m0 = tid * 16;
+  for (int p = 0; p < n_prn; p++) {
+    const float2 *__restrict__ cs = spectra + (size_t)p * N;
+    float acc[16];       // MODE 1: running sum of magnitudes of this thread's 16 code phases
+    float2 dacc[16], prev[16];
+#pragma unroll
+    for (int c = 0; c < 16; c++) { acc[c] = 0.f; dacc[c] = make_float2(0.f, 0.f); prev[c] = make_float2(0.f, 0.f); }
+    for (int g = 0; g < n_groups; g++) {
+      int lt = tid;
+      asm volatile("" : "+v"(lt));
+      const float2 *__restrict__ zc = zbase + (size_t)g * N;
+      float2 v[16];
+      for_each_first_pass_input<PL>(lt, [&](int slot, int, int e) { v[slot] = cmul(zc[e], cs[e]); });
+      // forward FFT of conj(Z) C = conj(y) * N: the row is written as y (conjugated back, scaled)
+      auto st = [&](int, int k, float2 y) { lds[PL::idx(0, k)] = make_float2(y.x * inv_n, -y.y * inv_n); };
+      TwTable twt{tw};
+      fft_block_preloaded<PL, true>(v, lds, twt, lt, st);
+      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < 16; c++) {
+        const float2 y = lds[PL::idx(0, m0 + c)];
+        if (MODE == 1) {
+          acc[c] += sqrtf(y.x * y.x + y.y * y.y);
+        } else {
+          if (g > 0) {  // diff_acc += y * conj(prev)   (mult / get_conj / add of gnss_codes.c:8-25)
+            dacc[c].x += y.x * prev[c].x - y.y * (-prev[c].y);
+            dacc[c].y += y.x * (-prev[c].y) + y.y * prev[c].x;
+          }
+          prev[c] = y;
+        }
+      }
+      __syncthreads();  // the row is consumed: the next group's IFFT may overwrite it
+    }
+#pragma unroll
+    for (int c = 0; c < 16; c++)
+      magl[mag_idx(m0 + c)] = (MODE == 1) ? acc[c] : sqrtf(dacc[c].x * dacc[c].x + dacc[c].y * dacc[c].y);
+    __syncthreads();
+    auto mag = [&](int m) -> float { return magl[mag_idx(m)]; };
+    const Top2 t = top2_scan<T, 16, true>(mag, N, sep, tid, xch);
+    if (tid == 0) finish_row(t, mag, N, d, prns[p], all + ((size_t)scene * n_prn + p) * n_dop + d);
+    __syncthreads();
   }
 }
 
@@ -466,6 +567,31 @@ hipError_t launch_acquire(const gnss_acq_plan *pl, const void *sig, int packed, 
   if (e != hipSuccess) return e;
   k<<<dim3(d1 - d0, n_scenes), PL::T, lds, s>>>(sig, packed, pl->spectra_dev, pl->tw, pl->dops_dev, pl->prns_dev, pl->n_prn, pl->n_dop, d0,
                                                 pl->n_ms, pl->spm, pl->spc, pl->pk_sep, all);
+  return hipGetLastError();
+}
+
+template <int LOGN>
+hipError_t launch_groups(const gnss_acq_plan *pl, const void *sig, int packed, uint32_t n_scenes, int d0, int d1, int mode, int n_groups,
+                         float2 *work, gnss_acq_result *all, hipStream_t s)
+{
+  using PL = GPlan<LOGN>;
+  const size_t lds_a = PL::LDS_BYTES + kMaxMs * sizeof(float2);
+  const size_t lds_b = PL::LDS_BYTES + 3 * ((PL::T + 63) / 64) * 8 + 16;
+  auto ka = gnss_group_spectra_kernel<LOGN>;
+  hipError_t e = hipFuncSetAttribute((const void *)ka, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a);
+  if (e != hipSuccess) return e;
+  ka<<<dim3(d1 - d0, n_scenes, n_groups), PL::T, lds_a, s>>>(sig, packed, pl->tw, pl->dops_dev, d0, pl->n_ms, pl->n_ms / n_groups, pl->spm,
+                                                             pl->spc, work);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  if (mode == 1) {
+    auto kb = gnss_accumulate_kernel<LOGN, 1>;
+    if ((e = hipFuncSetAttribute((const void *)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b)) != hipSuccess) return e;
+    kb<<<dim3(d1 - d0, n_scenes), PL::T, lds_b, s>>>(work, pl->spectra_dev, pl->tw, pl->prns_dev, pl->n_prn, pl->n_dop, d0, n_groups, pl->pk_sep, all);
+  } else {
+    auto kb = gnss_accumulate_kernel<LOGN, 2>;
+    if ((e = hipFuncSetAttribute((const void *)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b)) != hipSuccess) return e;
+    kb<<<dim3(d1 - d0, n_scenes), PL::T, lds_b, s>>>(work, pl->spectra_dev, pl->tw, pl->prns_dev, pl->n_prn, pl->n_dop, d0, n_groups, pl->pk_sep, all);
+  }
   return hipGetLastError();
 }
 
@@ -590,6 +716,41 @@ arm_status gnss_acquire_ors_dev(const gnss_acq_plan *pl, const uint8_t *ors_dev,
                                 gnss_acq_result *all_dev, gnss_acq_result *best_dev, void *stream)
 {
   return acquire_any(pl, ors_dev, 1, n_scenes, dop_begin, dop_end, all_dev, best_dev, stream, "gnss_acquire_ors_dev");
+}
+
+size_t gnss_acq_workspace_bytes(const gnss_acq_plan *pl, uint32_t n_scenes, uint32_t n_dop_bins, uint32_t n_groups)
+{
+  return pl ? (size_t)n_scenes * n_dop_bins * n_groups * (size_t)pl->fft_len * sizeof(float2) : 0;
+}
+
+arm_status gnss_acquire_groups_dev(const gnss_acq_plan *pl, const float *signal_dev, uint32_t n_scenes, uint32_t dop_begin, uint32_t dop_end,
+                                   int32_t mode, uint32_t n_groups, void *work_dev, gnss_acq_result *all_dev, gnss_acq_result *best_dev,
+                                   void *stream)
+{
+  const char *who = "gnss_acquire_groups_dev";
+  if (!pl || !signal_dev || !all_dev || !work_dev) { set_error("%s: null argument", who); return ARM_MATH_ARGUMENT_ERROR; }
+  if (mode != GNSS_ACQ_NONCOHERENT && mode != GNSS_ACQ_DIFFERENTIAL) { set_error("%s: mode must be GNSS_ACQ_NONCOHERENT or GNSS_ACQ_DIFFERENTIAL", who); return ARM_MATH_ARGUMENT_ERROR; }
+  if (n_groups == 0 || n_groups > 65535 || (uint32_t)pl->n_ms % n_groups != 0 || (mode == GNSS_ACQ_DIFFERENTIAL && n_groups < 2)) {
+    set_error("%s: n_groups must divide the plan's %d ms (and be >= 2 for the differential mode)", who, pl->n_ms);
+    return ARM_MATH_ARGUMENT_ERROR;
+  }
+  if (dop_begin > dop_end || dop_end > (uint32_t)pl->n_dop) {
+    set_error("%s: Doppler range [%u, %u) outside the plan's %d bins", who, dop_begin, dop_end, pl->n_dop);
+    return ARM_MATH_ARGUMENT_ERROR;
+  }
+  if (n_scenes > 65535) { set_error("%s: at most 65535 scenes per call", who); return ARM_MATH_ARGUMENT_ERROR; }
+  if (n_scenes == 0 || dop_begin == dop_end) return ARM_MATH_SUCCESS;
+  if (!plan_on_device(pl, who)) return ARM_MATH_ARGUMENT_ERROR;
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = GNSS_DISPATCH(launch_groups, pl->logn, pl, signal_dev, 0, n_scenes, (int)dop_begin, (int)dop_end, (int)mode, (int)n_groups,
+                               reinterpret_cast<float2 *>(work_dev), all_dev, s);
+  if (!hip_ok(e, "gnss group kernels launch")) return ARM_MATH_ARGUMENT_ERROR;
+  if (best_dev) {
+    const int rows = (int)n_scenes * pl->n_prn;
+    gnss_best_kernel<<<(rows + 255) / 256, 256, 0, s>>>(all_dev, best_dev, rows, pl->n_dop, (int)dop_begin, (int)dop_end);
+    if (!hip_ok(hipGetLastError(), "gnss_best_kernel launch")) return ARM_MATH_ARGUMENT_ERROR;
+  }
+  return ARM_MATH_SUCCESS;
 }
 
 arm_status gnss_decode_ors_iq_dev(const uint8_t *data_dev, uint32_t byte_length, float *iqs_dev, void *stream)

@@ -317,6 +317,18 @@ arm_status gnss_acquire_dev(const gnss_acq_plan *plan, const float32_t *signal_d
  * decode happens inside the wipe-off load, the float signal never exists in memory. */
 arm_status gnss_acquire_ors_dev(const gnss_acq_plan *plan, const uint8_t *ors_dev, uint32_t n_scenes, uint32_t dop_begin,
                                 uint32_t dop_end, gnss_acq_result *all_dev, gnss_acq_result *best_dev, void *stream);
+/* Non-coherent and differential accumulation.  The plan's n_ms milliseconds are cut
+ * into n_groups groups (n_groups divides n_ms); each group is folded coherently and correlated, then
+ *   GNSS_ACQ_NONCOHERENT:  r[m] = sum_g |y_g[m]|                        (NCI loop, CMSIS/CMSIS.cpp:915-943)
+ *   GNSS_ACQ_DIFFERENTIAL: r[m] = |sum_{g>=1} y_g[m] conj(y_{g-1}[m])|  (test_quasi_diff_pilot, :1030-1062)
+ * and find_top2_peaks_real / compute_snr_real / InterpolateCodePhase run on r (:948-951).  work_dev =
+ * gnss_acq_workspace_bytes(plan, n_scenes, dop_end - dop_begin, n_groups) bytes of caller-owned device
+ * memory (the group spectra); nothing is allocated. */
+typedef enum { GNSS_ACQ_COHERENT = 0, GNSS_ACQ_NONCOHERENT = 1, GNSS_ACQ_DIFFERENTIAL = 2 } gnss_acq_mode;
+size_t gnss_acq_workspace_bytes(const gnss_acq_plan *plan, uint32_t n_scenes, uint32_t n_dop_bins, uint32_t n_groups);
+arm_status gnss_acquire_groups_dev(const gnss_acq_plan *plan, const float32_t *signal_dev, uint32_t n_scenes, uint32_t dop_begin,
+                                   uint32_t dop_end, int32_t mode, uint32_t n_groups, void *work_dev, gnss_acq_result *all_dev,
+                                   gnss_acq_result *best_dev, void *stream);
 /* DecodeOrsIQCplx itself (CMSIS/CMSIS.cpp:465-485) on device pointers: 2 * byte_length complex samples out */
 arm_status gnss_decode_ors_iq_dev(const uint8_t *data_dev, uint32_t byte_length, float32_t *iqs_dev, void *stream);
 /* host pointers, all bins; `all` may be NULL */

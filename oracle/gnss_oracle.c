@@ -233,6 +233,101 @@ int orc_acquire_fused(const orc_c32 *signal, int n_ms, int spm, int fft_len, int
   return 0;
 }
 
+/* compute_snr_real (gnss_codes.c:1127-1142) */
+static double snr_real(const float *row, int n, double peak, int peak_loc)
+{
+  double sum = 0;
+  for (int i = 0; i < n; i++)
+    if (abs(i - peak_loc) > 2) sum += row[i];
+  return 10.0 * log10(peak / (sum / (n - 5)));
+}
+
+/* Accumulation over groups of milliseconds: mode 1 = non-coherent sum of magnitudes
+ * (NCI loop, CMSIS/CMSIS.cpp:915-943: nci_sum[i] += mag(up_prod[i])), mode 2 = differential
+ * (test_quasi_diff_pilot, :1047-1062: diff_acc += y * conj(prev), then mag).  Groups are folded
+ * coherently with the wipe-off of orc_acquire_fused; the row goes through find_top2_peaks_real,
+ * compute_snr_real and InterpolateCodePhase (:948-951; neighbours taken circularly, the reference
+ * indexes idx1 +- 1 without a wrap). */
+int orc_acquire_groups(const orc_c32 *signal, int n_ms, int spm, int fft_len, int spc, const int *prns, int n_prn, const float *dopplers,
+                       int n_dop, int mode, int n_groups, orc_acq_result *best, orc_acq_result *all)
+{
+  if (spm > fft_len || n_ms < 1 || n_groups < 1 || n_ms % n_groups || (mode != 1 && mode != 2) || (mode == 2 && n_groups < 2)) return -1;
+  const int mpg = n_ms / n_groups;
+  double FS = 1.023e6 * spc;
+  orc_c32 *codes = (orc_c32 *)calloc((size_t)n_prn * fft_len, sizeof(orc_c32));
+  orc_c32 *Z = (orc_c32 *)malloc(sizeof(orc_c32) * (size_t)fft_len * n_groups);
+  orc_c32 *y = (orc_c32 *)malloc(sizeof(orc_c32) * (size_t)fft_len);
+  orc_c32 *prev = (orc_c32 *)malloc(sizeof(orc_c32) * (size_t)fft_len);
+  orc_c32 *dacc = (orc_c32 *)malloc(sizeof(orc_c32) * (size_t)fft_len);
+  float *row = (float *)malloc(sizeof(float) * (size_t)fft_len);
+  int *chips = (int *)malloc(sizeof(int) * (size_t)(fft_len + spc));
+  if (!codes || !Z || !y || !prev || !dacc || !row || !chips) return -1;
+  for (int p = 0; p < n_prn; p++) {
+    orc_c32 *c = codes + (size_t)p * fft_len;
+    orc_get_code(spm / spc, spc, prns[p], chips);
+    for (int n = 0; n < spm; n++) { c[n].r = (float)chips[n]; c[n].i = 0.0f; }
+    orc_fft_c32(fft_len, c, 1);
+    best[p].peak = -1.0f;
+  }
+  for (int d = 0; d < n_dop; d++) {
+    for (int g = 0; g < n_groups; g++) {
+      orc_c32 *z = Z + (size_t)g * fft_len;
+      memset(z, 0, sizeof(orc_c32) * (size_t)fft_len);
+      for (int b = g * mpg; b < (g + 1) * mpg; b++)
+        for (int m = 0; m < spm; m++) {
+          long n = (long)b * spm + m;
+          double cyc = (double)dopplers[d] * (double)n / FS;
+          cyc -= floor(cyc);
+          double th = 2.0 * ORC_PI * cyc;
+          float c = (float)cos(th), s = (float)sin(th);
+          float I = signal[n].r, Q = signal[n].i;
+          z[m].r += I * c + Q * s;
+          z[m].i += -I * s + Q * c;
+        }
+      orc_fft_c32(fft_len, z, 1);
+    }
+    for (int p = 0; p < n_prn; p++) {
+      const orc_c32 *c = codes + (size_t)p * fft_len;
+      memset(row, 0, sizeof(float) * (size_t)fft_len);
+      memset(dacc, 0, sizeof(orc_c32) * (size_t)fft_len);
+      for (int g = 0; g < n_groups; g++) {
+        const orc_c32 *z = Z + (size_t)g * fft_len;
+        for (int i = 0; i < fft_len; i++) {
+          float ar = z[i].r, ai = z[i].i, br = c[i].r, bi = -c[i].i;
+          y[i].r = ar * br - ai * bi;
+          y[i].i = ar * bi + ai * br;
+        }
+        orc_fft_c32(fft_len, y, 0);
+        if (mode == 1) {
+          for (int i = 0; i < fft_len; i++) row[i] += c32_mag(y[i]);
+        } else {
+          if (g > 0)
+            for (int i = 0; i < fft_len; i++) {
+              float br = prev[i].r, bi = -prev[i].i;
+              dacc[i].r += y[i].r * br - y[i].i * bi;
+              dacc[i].i += y[i].r * bi + y[i].i * br;
+            }
+          memcpy(prev, y, sizeof(orc_c32) * (size_t)fft_len);
+        }
+      }
+      if (mode == 2)
+        for (int i = 0; i < fft_len; i++) row[i] = c32_mag(dacc[i]);
+      orc_top2 pk;
+      orc_find_top2_peaks_real(row, fft_len, 3, &pk);
+      orc_acq_result r;
+      r.peak = pk.val1; r.second = pk.val2; r.code_phase = pk.idx1; r.second_phase = pk.idx2;
+      r.doppler_bin = d; r.prn = prns[p];
+      r.snr_db = (float)snr_real(row, fft_len, pk.val1, pk.idx1);
+      int e = (pk.idx1 + fft_len - 1) % fft_len, l = (pk.idx1 + 1) % fft_len;
+      r.code_phase_interp = (float)orc_interpolate_code_phase((uint32_t)pk.idx1, row[e], pk.val1, row[l]);
+      if (all) all[(size_t)p * n_dop + d] = r;
+      if (r.peak > best[p].peak) best[p] = r;
+    }
+  }
+  free(codes); free(Z); free(y); free(prev); free(dacc); free(row); free(chips);
+  return 0;
+}
+
 /* DecodeOrsIQCplx (CMSIS/CMSIS.cpp:465-485): 2-bit I/Q, two complex samples per byte */
 void orc_decode_ors_iq(const uint8_t *data, uint32_t byte_length, orc_c32 *iqs)
 {

@@ -157,7 +157,7 @@ def ca_code(prn, spc=4, num=1023):
     return out
 
 
-def make_gps_scene(seed=0x5EED0006, n_ms=10, spc=4, sigma=2.0, offset_hz=0.0, svs=None, amp=1.0):
+def make_gps_scene(seed=0x5EED0006, n_ms=10, spc=4, sigma=2.0, offset_hz=0.0, svs=None, amp=1.0, signs=None):
     """Complex f32 samples, n_ms * 1023 * spc of them: sum of code(prn) delayed by `phase` samples
     with carrier e^{+j 2 pi f n / FS}, plus white Gaussian noise of std sigma per component."""
     svs = svs or GPS_SCENE
@@ -167,7 +167,8 @@ def make_gps_scene(seed=0x5EED0006, n_ms=10, spc=4, sigma=2.0, offset_hz=0.0, sv
     x = np.zeros(n.size, np.complex128)
     for prn, ph, fd in zip(svs["prns"], svs["phases"], svs["dopplers"]):
         c = ca_code(prn, spc).astype(np.float64)
-        x += amp * c[(n - ph) % spm] * np.exp(2j * np.pi * (fd + offset_hz) * n / fs)
+        bits = 1.0 if signs is None else np.repeat(np.asarray(signs, np.float64), spm)   # data-bit sign per millisecond
+        x += amp * bits * c[(n - ph) % spm] * np.exp(2j * np.pi * (fd + offset_hz) * n / fs)
     g = rng(seed)
     x += sigma * (g.standard_normal(n.size) + 1j * g.standard_normal(n.size))
     out = np.empty((n.size, 2), np.float32)
@@ -186,6 +187,19 @@ def oracle_acquire(signal, n_ms, spm, fft_len, spc, prns, dopplers, want_all=Tru
     rc = oracle().orc_acquire_fused(sig.ctypes.data_as(ctypes.c_void_p), n_ms, spm, fft_len, spc, ptr(prns, c_i32), len(prns),
                                     ptr(dopplers, c_f), len(dopplers), best.ctypes.data_as(ctypes.c_void_p),
                                     allc.ctypes.data_as(ctypes.c_void_p) if want_all else None)
+    assert rc == 0
+    return best, allc
+
+
+def oracle_acquire_groups(signal, n_ms, spm, fft_len, spc, prns, dopplers, mode, n_groups):
+    prns = np.ascontiguousarray(prns, np.int32)
+    dopplers = np.ascontiguousarray(dopplers, np.float32)
+    best = np.zeros(len(prns), ACQ_DTYPE)
+    allc = np.zeros((len(prns), len(dopplers)), ACQ_DTYPE)
+    sig = np.ascontiguousarray(signal, np.float32)
+    rc = oracle().orc_acquire_groups(sig.ctypes.data_as(ctypes.c_void_p), n_ms, spm, fft_len, spc, ptr(prns, c_i32), len(prns),
+                                     ptr(dopplers, c_f), len(dopplers), mode, n_groups, best.ctypes.data_as(ctypes.c_void_p),
+                                     allc.ctypes.data_as(ctypes.c_void_p))
     assert rc == 0
     return best, allc
 

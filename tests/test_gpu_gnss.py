@@ -333,3 +333,73 @@ def test_acquisition_on_packed_recordings_equals_decoded_float_path():
         b = fbest[0][prn - 1]                                             # 2-bit quantisation keeps the scene detectable
         assert H.DOPPLER_GRID[b["doppler_bin"]] == fd and ph <= b["code_phase"] <= ph + 4
     pl.close()
+
+
+# ------------------------------------------------------------------ 8(f).4: non-coherent / differential accumulation
+SIGNS = [1, 1, -1, -1, 1, -1, 1, -1, -1, 1]         # data-bit flips, five milliseconds each sign: the coherent sum cancels
+
+
+def _groups_dev(pl, sig, mode, n_groups, d0=0, d1=None):
+    import torch
+    import gpu_util as G
+    fa, lib = _lib()
+    fft_len, spm, n_ms, spc = pl.geo
+    sig = np.ascontiguousarray(sig, np.float32).reshape(-1, n_ms * spm, 2)
+    ns, npn, nd = sig.shape[0], len(pl.prns), len(pl.dops)
+    d1 = nd if d1 is None else d1
+    t = _dev(sig)
+    nbytes = lib.gnss_acq_workspace_bytes(pl.p, ns, d1 - d0, n_groups)
+    assert nbytes == ns * (d1 - d0) * n_groups * fft_len * 8
+    work = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    allc = torch.zeros((ns, npn, nd, 8), dtype=torch.int32, device="cuda")
+    best = torch.zeros((ns, npn, 8), dtype=torch.int32, device="cuda")
+    G.check(lib.gnss_acquire_groups_dev(pl.p, ctypes.c_void_p(t.data_ptr()), ns, d0, d1, mode, n_groups, ctypes.c_void_p(work.data_ptr()),
+                                        ctypes.c_void_p(allc.data_ptr()), ctypes.c_void_p(best.data_ptr()), G.stream_ptr()))
+    torch.cuda.synchronize()
+    return (best.cpu().numpy().view(H.ACQ_DTYPE).reshape(ns, npn), allc.cpu().numpy().view(H.ACQ_DTYPE).reshape(ns, npn, nd))
+
+
+@pytest.mark.parametrize("mode,n_groups", [(1, 10), (1, 5), (2, 10), (2, 2), (1, 1)])
+def test_grouped_accumulation_vs_oracle(mode, n_groups):
+    prns = np.array([3, 7, 9, 11, 19, 22, 30, 31], np.int32)
+    dops = H.DOPPLER_GRID[::4]                                         # 11 bins, contains all six SV Dopplers? no: only some
+    dops = np.array(sorted(set(dops.tolist()) | set(H.GPS_SCENE["dopplers"])), np.float32)
+    scenes = [H.make_gps_scene(seed=31, sigma=1.0, signs=SIGNS), H.make_gps_scene(seed=32, sigma=1.0)]
+    pl = Plan(4096, 4092, 10, 4, prns, dops)
+    best, allc = _groups_dev(pl, np.stack(scenes), mode, n_groups)
+    for i, s in enumerate(scenes):
+        wb, wa = H.oracle_acquire_groups(s, 10, 4092, 4096, 4, prns, dops, mode, n_groups)
+        _same_cells(allc[i], wa, "mode %d groups %d scene %d" % (mode, n_groups, i))
+        _same_cells(best[i], wb, "best")
+    if n_groups == 10:
+        # with a sign flip in most milliseconds the 1-ms groups still find every SV; the coherent sum does not find all
+        cb, _ = pl.acquire_dev(scenes[0])
+        def found(b):
+            n = 0
+            for prn, ph, fd in zip(H.GPS_SCENE["prns"], H.GPS_SCENE["phases"], H.GPS_SCENE["dopplers"]):
+                r = b[list(prns).index(prn)]
+                n += int(dops[r["doppler_bin"]] == fd and ph <= r["code_phase"] <= ph + 4)
+            return n
+        assert found(best[0]) == 6 and found(cb[0]) < 6
+    pl.close()
+
+
+def test_grouped_accumulation_errors_and_sharding():
+    import torch
+    fa, lib = _lib()
+    pl = Plan(4096, 4092, 10, 4, [5, 6], H.DOPPLER_GRID[:6])
+    sig = H.make_gps_scene(seed=33, sigma=1.0)
+    full_b, full_a = _groups_dev(pl, sig, 1, 5)
+    b0, a0 = _groups_dev(pl, sig, 1, 5, 0, 2)
+    b1, a1 = _groups_dev(pl, sig, 1, 5, 2, 6)
+    assert a0[0][:, :2].tobytes() == full_a[0][:, :2].tobytes() and a1[0][:, 2:].tobytes() == full_a[0][:, 2:].tobytes()
+    t = torch.zeros((40920, 2), device="cuda")
+    w = torch.zeros(8, device="cuda")
+    o = torch.zeros((2, 6, 8), dtype=torch.int32, device="cuda")
+    args = lambda mode, ng: (pl.p, ctypes.c_void_p(t.data_ptr()), 1, 0, 6, mode, ng, ctypes.c_void_p(w.data_ptr()), ctypes.c_void_p(o.data_ptr()), None, None)
+    bad = fa.ARM_MATH_ARGUMENT_ERROR
+    assert lib.gnss_acquire_groups_dev(*args(0, 5)) == bad          # coherent mode has its own entry point
+    assert lib.gnss_acquire_groups_dev(*args(1, 3)) == bad          # 3 does not divide 10 ms
+    assert lib.gnss_acquire_groups_dev(*args(2, 1)) == bad          # differential needs two groups
+    assert lib.gnss_acquire_groups_dev(pl.p, ctypes.c_void_p(t.data_ptr()), 1, 0, 6, 1, 5, None, ctypes.c_void_p(o.data_ptr()), None, None) == bad
+    pl.close()
