@@ -134,6 +134,9 @@ struct Plan {
   static constexpr size_t LDS_BYTES = (size_t)LDS_ELEMS * sizeof(float2);
   // LDS index of point e of sequence t
   static __device__ __forceinline__ int idx(int t, int e) { return t * SEQ_STRIDE + e + ((e >> 4) << 1); }
+  // idx(t, e + c) - idx(t, e) for a compile-time c whose set bits are disjoint from e's (true for
+  // the r << LNR / r << LNS strides of a pass): a constant, so it folds into the DS offset field
+  static constexpr int delta(int c) { return c + ((c >> 4) << 1); }
 };
 
 // Load tag: the caller has already placed the first pass's inputs in v[] (same order the gather
@@ -220,13 +223,13 @@ __device__ __forceinline__ void fft_pass(float2 *v, float2 *lds, const TW &tw, i
   for (int q = 0; q < NB; q++) {
     const int w = tid + q * T;
     const int t = w >> LNR, j = w & ((1 << LNR) - 1);
+    const int base = PL::idx(t, j);  // one address per butterfly; the legs are compile-time offsets
 #pragma unroll
     for (int r = 0; r < R; r++) {
-      const int e = j + (r << LNR);
       if constexpr (FIRST) {
-        if constexpr (!std::is_same<Load, Preloaded>::value) v[q * R + r] = ld(t, e);
+        if constexpr (!std::is_same<Load, Preloaded>::value) v[q * R + r] = ld(t, j + (r << LNR));
       } else {
-        v[q * R + r] = lds[PL::idx(t, e)];
+        v[q * R + r] = lds[base + PL::delta(r << LNR)];
       }
     }
   }
@@ -258,14 +261,16 @@ __device__ __forceinline__ void fft_pass(float2 *v, float2 *lds, const TW &tw, i
       for (int r = 0; r < R; r++) st(t, j0 + (r << LNS), v[q * R + r]);
     } else if (FIRST && R >= 2) {
       // NS == 1: R consecutive points per butterfly -> 16-byte LDS stores
+      const int base = PL::idx(t, j * R);
 #pragma unroll
       for (int r = 0; r < R; r += 2) {
-        *reinterpret_cast<float4 *>(&lds[PL::idx(t, j * R + r)]) =
+        *reinterpret_cast<float4 *>(&lds[base + PL::delta(r)]) =
             make_float4(v[q * R + r].x, v[q * R + r].y, v[q * R + r + 1].x, v[q * R + r + 1].y);
       }
     } else {
+      const int base = PL::idx(t, j0);
 #pragma unroll
-      for (int r = 0; r < R; r++) lds[PL::idx(t, j0 + (r << LNS))] = v[q * R + r];
+      for (int r = 0; r < R; r++) lds[base + PL::delta(r << LNS)] = v[q * R + r];
     }
   }
   if (!LAST) __syncthreads();
