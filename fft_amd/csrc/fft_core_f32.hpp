@@ -209,8 +209,12 @@ struct TwRegs {
 
 // One pass.  P = pass index.  v holds the thread's 16 points: butterfly q (0..16/R-1), leg r at
 // v[q*R + r].
+// twc = this pass's twiddles (fetched during the previous pass), twn = filled with the next pass's
+// twiddles right before this pass's closing barrier: v[] is dead by then, so the loads cost no
+// registers, and their L1/L2 latency hides behind the barrier and the next gather instead of
+// stalling every pass (workgroups of 8192/16384-point transforms are too few per CU to hide it).
 template <class PL, int P, bool LDS_IN, bool LDS_OUT, class TW, class Load, class Store>
-__device__ __forceinline__ void fft_pass(float2 *v, float2 *lds, const TW &tw, int tid, Load &ld, Store &st)
+__device__ __forceinline__ void fft_pass(float2 *v, float2 *lds, const TW &tw, int tid, Load &ld, Store &st, const float2 *twc, float2 *twn)
 {
   constexpr int LOGN = PL::LOGN, T = PL::T;
   constexpr int LR = PL::lr(P), R = 1 << LR, NB = 16 / R;
@@ -239,11 +243,8 @@ __device__ __forceinline__ void fft_pass(float2 *v, float2 *lds, const TW &tw, i
     const int w = tid + q * T;
     const int j = w & ((1 << LNR) - 1);
     if (!FIRST) {
-      const int k = j & (NS - 1);
-      // W_{NS*R}^{r k} = tw[r * k * N/(NS*R)]
-      const int stepk = k << (LOGN - LNS - LR);
 #pragma unroll
-      for (int r = 1; r < R; r++) v[q * R + r] = cmul(v[q * R + r], tw.template get<P>(q * (R - 1) + r - 1, r * stepk));
+      for (int r = 1; r < R; r++) v[q * R + r] = cmul(v[q * R + r], twc[q * (R - 1) + r - 1]);
     }
     butterfly<R>(v + q * R);
   }
@@ -273,15 +274,26 @@ __device__ __forceinline__ void fft_pass(float2 *v, float2 *lds, const TW &tw, i
       for (int r = 0; r < R; r++) lds[base + PL::delta(r << LNS)] = v[q * R + r];
     }
   }
-  if (!LAST) __syncthreads();
+  if constexpr (!LAST) {
+    // next pass's twiddles: W_{NS*R}^{r k} = tw[r * k * N/(NS*R)], k = butterfly index mod NS
+    constexpr int LR1 = PL::lr(P + 1), R1 = 1 << LR1, NB1 = 16 / R1, LNS1 = PL::lns(P + 1), NS1 = 1 << LNS1, LNR1 = LOGN - LR1;
+#pragma unroll
+    for (int q = 0; q < NB1; q++) {
+      const int j = (tid + q * T) & ((1 << LNR1) - 1);
+      const int stepk = (j & (NS1 - 1)) << (LOGN - LNS1 - LR1);
+#pragma unroll
+      for (int r = 1; r < R1; r++) twn[q * (R1 - 1) + r - 1] = tw.template get<P + 1>(q * (R1 - 1) + r - 1, r * stepk);
+    }
+    __syncthreads();
+  }
 }
 
 template <class PL, int P, bool LDS_IN, bool LDS_OUT, class TW, class Load, class Store>
 struct PassLoop {
-  static __device__ __forceinline__ void run(float2 *v, float2 *lds, const TW &tw, int tid, Load &ld, Store &st)
+  static __device__ __forceinline__ void run(float2 *v, float2 *lds, const TW &tw, int tid, Load &ld, Store &st, float2 *twa, float2 *twb)
   {
-    fft_pass<PL, P, LDS_IN, LDS_OUT>(v, lds, tw, tid, ld, st);
-    if constexpr (P + 1 < PL::NPASS) PassLoop<PL, P + 1, LDS_IN, LDS_OUT, TW, Load, Store>::run(v, lds, tw, tid, ld, st);
+    fft_pass<PL, P, LDS_IN, LDS_OUT>(v, lds, tw, tid, ld, st, twa, twb);
+    if constexpr (P + 1 < PL::NPASS) PassLoop<PL, P + 1, LDS_IN, LDS_OUT, TW, Load, Store>::run(v, lds, tw, tid, ld, st, twb, twa);
   }
 };
 
@@ -294,8 +306,8 @@ struct PassLoop {
 template <class PL, bool LDS_IN, bool LDS_OUT, class TW, class Load, class Store>
 __device__ __forceinline__ void fft_block_tw(float2 *lds, const TW &tw, int tid, Load ld, Store st)
 {
-  float2 v[16];
-  PassLoop<PL, 0, LDS_IN, LDS_OUT, TW, Load, Store>::run(v, lds, tw, tid, ld, st);
+  float2 v[16], twa[15], twb[15];
+  PassLoop<PL, 0, LDS_IN, LDS_OUT, TW, Load, Store>::run(v, lds, tw, tid, ld, st, twa, twb);
 }
 
 template <class PL, bool LDS_IN, bool LDS_OUT, class Load, class Store>
@@ -310,7 +322,8 @@ template <class PL, bool LDS_OUT, class TW, class Store>
 __device__ __forceinline__ void fft_block_preloaded(float2 *v, float2 *lds, const TW &tw, int tid, Store st)
 {
   Preloaded ld;
-  PassLoop<PL, 0, false, LDS_OUT, TW, Preloaded, Store>::run(v, lds, tw, tid, ld, st);
+  float2 twa[15], twb[15];
+  PassLoop<PL, 0, false, LDS_OUT, TW, Preloaded, Store>::run(v, lds, tw, tid, ld, st, twa, twb);
 }
 
 }  // namespace armfft
