@@ -96,10 +96,18 @@ __global__ __launch_bounds__(Plan<LOGM>::T, 4) void rfft_f32_kernel(const float2
         return tr < batch ? in[(size_t)tr * M + e] : make_float2(0.f, 0.f);
       };
       auto st = [&](int t, int e, float2 v) { lds[PL::idx(t, e)] = v; };
+      // the split's (sin, cos) factors depend only on the thread: fetch them now, their latency
+      // hides behind the whole transform
+      constexpr int NSPLIT = PL::TPB * M / PL::T;  // = 16
+      float2 csr[NSPLIT];
+#pragma unroll
+      for (int i = 0; i < NSPLIT; i++) csr[i] = twr[(tid + i * PL::T) & (M - 1)];
       fft_block<PL, false, true>(lds, tw, tid, ld, st);
       __syncthreads();
       // split: bin k from Z[k] and Z[M-k]
-      for (int w = tid; w < PL::TPB * M; w += PL::T) {
+#pragma unroll
+      for (int i = 0; i < NSPLIT; i++) {
+        const int w = tid + i * PL::T;
         const int t = w >> LOGM, k = w & (M - 1);
         const uint32_t tr = t0 + t;
         const float2 A = lds[PL::idx(t, k)];
@@ -108,7 +116,7 @@ __global__ __launch_bounds__(Plan<LOGM>::T, 4) void rfft_f32_kernel(const float2
           o = make_float2(A.x + A.y, A.x - A.y);  // 0.5*((2 re) +- (2 im)), exact
         } else {
           const float2 B = lds[PL::idx(t, M - k)];
-          const float2 c = twr[k];  // (sin, cos)
+          const float2 c = csr[i];  // (sin, cos)
           const float a = B.x - A.x, b = B.y + A.y;
           o.x = 0.5f * (A.x + B.x + c.x * a + c.y * b);
           o.y = 0.5f * (A.y - B.y + c.y * a - c.x * b);
