@@ -38,6 +38,7 @@ __device__ __forceinline__ int scrambled_pos(int k)
 // workgroups per CU the kernel streams at the same rate as a plain in-place copy.
 template <int LOGN> struct Tune { static constexpr unsigned HMASK = 0; static constexpr int MINW = 4, WGPCU = 0; };
 template <> struct Tune<12> { static constexpr unsigned HMASK = 6; static constexpr int MINW = 2, WGPCU = 2; };
+template <> struct Tune<11> { static constexpr unsigned HMASK = 6; static constexpr int MINW = 2, WGPCU = 2; };
 
 template <int LOGN, bool INV>
 __global__ __launch_bounds__(Plan<LOGN>::T, Tune<LOGN>::MINW) void cfft_f32_kernel(float2 *__restrict__ data, const float2 *__restrict__ tw,
