@@ -17,7 +17,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def lib_path():
-    return os.path.join(_HERE, "lib", "libarmfft_mi355.so")
+    # ARMFFT_LIB: A/B runs of two builds of the library on one box (tools/, never set by tests)
+    return os.environ.get("ARMFFT_LIB") or os.path.join(_HERE, "lib", "libarmfft_mi355.so")
 
 
 class arm_cfft_instance_f32(Structure):

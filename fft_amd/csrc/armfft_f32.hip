@@ -36,9 +36,59 @@ __device__ __forceinline__ int scrambled_pos(int k)
 // 4096 points: the per-transform twiddle loads (30 per thread, L1/L2 hits) cost 20 % of the
 // run time of the non-persistent kernel; with both twiddled passes in registers and 2
 // workgroups per CU the kernel streams at the same rate as a plain in-place copy.
-template <int LOGN> struct Tune { static constexpr unsigned HMASK = 0; static constexpr int MINW = 4, WGPCU = 0; };
-template <> struct Tune<12> { static constexpr unsigned HMASK = 6; static constexpr int MINW = 2, WGPCU = 2; };
-template <> struct Tune<11> { static constexpr unsigned HMASK = 6; static constexpr int MINW = 2, WGPCU = 2; };
+//   PRE    persistent workgroups fetch their next transform inside the current one's last pass
+// 16384 points: 144 KiB of LDS leave room for one workgroup per CU, so nothing overlaps its load,
+// compute and store phases unless the workgroup does it itself (PRE).
+template <int LOGN> struct Tune { static constexpr unsigned HMASK = 0; static constexpr int MINW = 4, WGPCU = 0; static constexpr bool PRE = false; };
+template <> struct Tune<12> { static constexpr unsigned HMASK = 6; static constexpr int MINW = 2, WGPCU = 2; static constexpr bool PRE = false; };
+template <> struct Tune<11> { static constexpr unsigned HMASK = 6; static constexpr int MINW = 2, WGPCU = 2; static constexpr bool PRE = false; };
+template <> struct Tune<13> { static constexpr unsigned HMASK = 0; static constexpr int MINW = 4, WGPCU = 2; static constexpr bool PRE = true; };
+template <> struct Tune<14> { static constexpr unsigned HMASK = 0; static constexpr int MINW = 4, WGPCU = 1; static constexpr bool PRE = true; };
+
+// Persistent workgroup that fetches its next transform inside the current one's last pass
+// (Tune::PRE).  One transform per workgroup round (TPB == 1, g < ngroups == batch): no per-lane
+// guards and no branches between the memory instructions, so the compiler counts outstanding
+// loads and stores exactly and each wait covers only what it needs.
+template <int LOGN, bool INV, int ORDER, class TW>
+__device__ __forceinline__ void cfft_f32_prefetching(float2 *__restrict__ data, float2 *lds, const TW &twr, uint32_t ngroups, uint32_t g0,
+                                                     uint32_t gstep)
+{
+  using PL = Plan<LOGN>;
+  static_assert(PL::TPB == 1, "prefetching kernel: one transform per workgroup");
+  const float inv_n = 1.0f / (float)PL::N;
+  float2 v[16];
+  auto fetch = [&](float2 *dst, uint32_t g, int tid) {
+    const float2 *__restrict__ p = data + (size_t)g * PL::N;
+    for_each_first_pass_input<PL>(tid, [&](int slot, int, int e) {
+      float2 x = p[e];
+      if (INV) x.y = -x.y;
+      dst[slot] = x;
+    });
+  };
+  if (g0 < ngroups) fetch(v, g0, threadIdx.x);
+  // vmcnt(0): the loop is entered with nothing in flight, so the waits at its top are derived from
+  // the back edge alone (16 loads, then 16 stores that may stay in flight into the next round)
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  for (uint32_t g = g0; g < ngroups; g += gstep) {
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    float2 *__restrict__ p = data + (size_t)g * PL::N;
+    float2 nx[16];
+    // the last round re-reads its own transform instead of branching around the loads
+    const uint32_t gn = g + gstep < ngroups ? g + gstep : g;
+    auto hook = [&]() { fetch(nx, gn, tid); };
+    auto st = [&](int, int e, float2 x) {
+      if (INV) x = make_float2(x.x * inv_n, -x.y * inv_n);
+      if (ORDER == 1) e = scrambled_pos<LOGN>(e);
+      if (ORDER == 2) e = (int)(__brev((unsigned)e) >> (32 - LOGN));
+      p[e] = x;
+    };
+    fft_block_preloaded<PL, false>(v, lds, twr, tid, st, hook);
+#pragma unroll
+    for (int i = 0; i < 16; i++) v[i] = nx[i];
+    __syncthreads();  // the next transform's first LDS write must not overtake this one's last read
+  }
+}
 
 template <int LOGN, bool INV>
 __global__ __launch_bounds__(Plan<LOGN>::T, Tune<LOGN>::MINW) void cfft_f32_kernel(float2 *__restrict__ data, const float2 *__restrict__ tw,
@@ -51,6 +101,13 @@ __global__ __launch_bounds__(Plan<LOGN>::T, Tune<LOGN>::MINW) void cfft_f32_kern
   twr.tw = tw;
   twr.preload(threadIdx.x);
   const uint32_t g0 = blockIdx.x + blockIdx.y * gridDim.x, gstep = gridDim.x * gridDim.y;
+  if constexpr (Tune<LOGN>::PRE) {
+    // output order resolved once per launch, not per store: no branches between the stores
+    if (order == 0) cfft_f32_prefetching<LOGN, INV, 0>(data, lds, twr, ngroups, g0, gstep);
+    else if (order == 1) cfft_f32_prefetching<LOGN, INV, 1>(data, lds, twr, ngroups, g0, gstep);
+    else cfft_f32_prefetching<LOGN, INV, 2>(data, lds, twr, ngroups, g0, gstep);
+    return;
+  }
   for (uint32_t g = g0; g < ngroups; g += gstep) {
     int tid = threadIdx.x;
     if (Tune<LOGN>::WGPCU) asm volatile("" : "+v"(tid));  // keep per-thread address math inside the loop

@@ -213,8 +213,18 @@ struct TwRegs {
 // twiddles right before this pass's closing barrier: v[] is dead by then, so the loads cost no
 // registers, and their L1/L2 latency hides behind the barrier and the next gather instead of
 // stalling every pass (workgroups of 8192/16384-point transforms are too few per CU to hide it).
-template <class PL, int P, bool LDS_IN, bool LDS_OUT, class TW, class Load, class Store>
-__device__ __forceinline__ void fft_pass(float2 *v, float2 *lds, const TW &tw, int tid, Load &ld, Store &st, const float2 *twc, float2 *twn)
+//
+// hook() runs in the LAST pass between the twiddle multiplies and the butterflies: from there on this
+// transform no longer touches HBM until its stores, so a persistent kernel issues the next
+// transform's loads there -- ahead of this one's stores in the memory queues -- and their latency
+// and transfer overlap the last butterflies and the store drain.
+struct NoHook {
+  __device__ __forceinline__ void operator()() const {}
+};
+
+template <class PL, int P, bool LDS_IN, bool LDS_OUT, class TW, class Load, class Store, class Hook>
+__device__ __forceinline__ void fft_pass(float2 *v, float2 *lds, const TW &tw, int tid, Load &ld, Store &st, const float2 *twc, float2 *twn,
+                                         Hook &hook)
 {
   constexpr int LOGN = PL::LOGN, T = PL::T;
   constexpr int LR = PL::lr(P), R = 1 << LR, NB = 16 / R;
@@ -238,16 +248,21 @@ __device__ __forceinline__ void fft_pass(float2 *v, float2 *lds, const TW &tw, i
     }
   }
   // ---- twiddle + butterfly ----
+  if (!FIRST) {
 #pragma unroll
-  for (int q = 0; q < NB; q++) {
-    const int w = tid + q * T;
-    const int j = w & ((1 << LNR) - 1);
-    if (!FIRST) {
+    for (int q = 0; q < NB; q++) {
 #pragma unroll
       for (int r = 1; r < R; r++) v[q * R + r] = cmul(v[q * R + r], twc[q * (R - 1) + r - 1]);
     }
-    butterfly<R>(v + q * R);
   }
+  if constexpr (LAST && !std::is_same<Hook, NoHook>::value) {
+    // twc is dead: the hook's registers take its place (and must not be scheduled any earlier)
+    __builtin_amdgcn_sched_barrier(0);
+    hook();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int q = 0; q < NB; q++) butterfly<R>(v + q * R);
   // ---- scatter ----
   // source and destination both in LDS: every read of this pass must finish before any write
   if ((!FIRST || LDS_IN) && (!LAST || LDS_OUT)) __syncthreads();
@@ -288,12 +303,13 @@ __device__ __forceinline__ void fft_pass(float2 *v, float2 *lds, const TW &tw, i
   }
 }
 
-template <class PL, int P, bool LDS_IN, bool LDS_OUT, class TW, class Load, class Store>
+template <class PL, int P, bool LDS_IN, bool LDS_OUT, class TW, class Load, class Store, class Hook>
 struct PassLoop {
-  static __device__ __forceinline__ void run(float2 *v, float2 *lds, const TW &tw, int tid, Load &ld, Store &st, float2 *twa, float2 *twb)
+  static __device__ __forceinline__ void run(float2 *v, float2 *lds, const TW &tw, int tid, Load &ld, Store &st, float2 *twa, float2 *twb,
+                                             Hook &hook)
   {
-    fft_pass<PL, P, LDS_IN, LDS_OUT>(v, lds, tw, tid, ld, st, twa, twb);
-    if constexpr (P + 1 < PL::NPASS) PassLoop<PL, P + 1, LDS_IN, LDS_OUT, TW, Load, Store>::run(v, lds, tw, tid, ld, st, twb, twa);
+    fft_pass<PL, P, LDS_IN, LDS_OUT>(v, lds, tw, tid, ld, st, twa, twb, hook);
+    if constexpr (P + 1 < PL::NPASS) PassLoop<PL, P + 1, LDS_IN, LDS_OUT, TW, Load, Store, Hook>::run(v, lds, tw, tid, ld, st, twb, twa, hook);
   }
 };
 
@@ -307,7 +323,8 @@ template <class PL, bool LDS_IN, bool LDS_OUT, class TW, class Load, class Store
 __device__ __forceinline__ void fft_block_tw(float2 *lds, const TW &tw, int tid, Load ld, Store st)
 {
   float2 v[16], twa[15], twb[15];
-  PassLoop<PL, 0, LDS_IN, LDS_OUT, TW, Load, Store>::run(v, lds, tw, tid, ld, st, twa, twb);
+  NoHook hook;
+  PassLoop<PL, 0, LDS_IN, LDS_OUT, TW, Load, Store, NoHook>::run(v, lds, tw, tid, ld, st, twa, twb, hook);
 }
 
 template <class PL, bool LDS_IN, bool LDS_OUT, class Load, class Store>
@@ -317,13 +334,13 @@ __device__ __forceinline__ void fft_block(float2 *lds, const float2 *__restrict_
   fft_block_tw<PL, LDS_IN, LDS_OUT>(lds, t, tid, ld, st);
 }
 
-// Same with the first pass's inputs already in v[16] (see Preloaded).
-template <class PL, bool LDS_OUT, class TW, class Store>
-__device__ __forceinline__ void fft_block_preloaded(float2 *v, float2 *lds, const TW &tw, int tid, Store st)
+// Same with the first pass's inputs already in v[16] (see Preloaded); hook: see fft_pass.
+template <class PL, bool LDS_OUT, class TW, class Store, class Hook = NoHook>
+__device__ __forceinline__ void fft_block_preloaded(float2 *v, float2 *lds, const TW &tw, int tid, Store st, Hook hook = Hook())
 {
   Preloaded ld;
   float2 twa[15], twb[15];
-  PassLoop<PL, 0, false, LDS_OUT, TW, Preloaded, Store>::run(v, lds, tw, tid, ld, st, twa, twb);
+  PassLoop<PL, 0, false, LDS_OUT, TW, Preloaded, Store, Hook>::run(v, lds, tw, tid, ld, st, twa, twb, hook);
 }
 
 }  // namespace armfft
