@@ -36,21 +36,34 @@ __device__ __forceinline__ int scrambled_pos(int k)
 // 4096 points: the per-transform twiddle loads (30 per thread, L1/L2 hits) cost 20 % of the
 // run time of the non-persistent kernel; with both twiddled passes in registers and 2
 // workgroups per CU the kernel streams at the same rate as a plain in-place copy.
-//   PRE    persistent workgroups fetch their next transform inside the current one's last pass
-// 16384 points: 144 KiB of LDS leave room for one workgroup per CU, so nothing overlaps its load,
-// compute and store phases unless the workgroup does it itself (PRE).
-template <int LOGN> struct Tune { static constexpr unsigned HMASK = 0; static constexpr int MINW = 4, WGPCU = 0; static constexpr bool PRE = false; };
-template <> struct Tune<12> { static constexpr unsigned HMASK = 6; static constexpr int MINW = 2, WGPCU = 2; static constexpr bool PRE = false; };
-template <> struct Tune<11> { static constexpr unsigned HMASK = 6; static constexpr int MINW = 2, WGPCU = 2; static constexpr bool PRE = false; };
-template <> struct Tune<13> { static constexpr unsigned HMASK = 0; static constexpr int MINW = 4, WGPCU = 2; static constexpr bool PRE = true; };
-template <> struct Tune<14> { static constexpr unsigned HMASK = 0; static constexpr int MINW = 4, WGPCU = 1; static constexpr bool PRE = true; };
+//   PRE    persistent workgroups fetch their next transform while the current one is in flight:
+//          the loads are issued in pass HP (after its twiddle multiplies), ahead of the current
+//          transform's stores in the memory queues
+//   LAZYMASK  passes whose twiddles come from register-held powers (TwPow) instead of the table
+// 8192 points: one workgroup per CU with 256 VGPRs per thread holds the current transform, the
+// whole next one and the twiddle bases; nothing touches vector memory inside the transform, so
+// the prefetch issued in pass 0 stays in flight across all passes (gfx9 has one in-order vmcnt:
+// a twiddle load after it would have to wait for it).
+// 16384 points: 1024 threads cap the kernel at 128 VGPRs (and 144 KiB of LDS at one workgroup per
+// CU); the prefetch fits only in the last pass, table twiddles.  TwPow variants of this size
+// (any HP) spill, and a spilled prefetch register means wait-for-everything right at the load.
+struct TuneBase {
+  static constexpr unsigned HMASK = 0, LAZYMASK = 0;
+  static constexpr int MINW = 4, WGPCU = 0, HP = 0;
+  static constexpr bool PRE = false;
+};
+template <int LOGN> struct Tune : TuneBase {};
+template <> struct Tune<11> : TuneBase { static constexpr unsigned HMASK = 6; static constexpr int MINW = 2, WGPCU = 2; };
+template <> struct Tune<12> : TuneBase { static constexpr unsigned HMASK = 6; static constexpr int MINW = 2, WGPCU = 2; };
+template <> struct Tune<13> : TuneBase { static constexpr unsigned LAZYMASK = ~0u; static constexpr int MINW = 2, WGPCU = 1, HP = 0; static constexpr bool PRE = true; };
+template <> struct Tune<14> : TuneBase { static constexpr int WGPCU = 1, HP = 3; static constexpr bool PRE = true; };
 
-// Persistent workgroup that fetches its next transform inside the current one's last pass
+// Persistent workgroup that fetches its next transform while the current one is in flight
 // (Tune::PRE).  One transform per workgroup round (TPB == 1, g < ngroups == batch): no per-lane
 // guards and no branches between the memory instructions, so the compiler counts outstanding
 // loads and stores exactly and each wait covers only what it needs.
 template <int LOGN, bool INV, int ORDER, class TW>
-__device__ __forceinline__ void cfft_f32_prefetching(float2 *__restrict__ data, float2 *lds, const TW &twr, uint32_t ngroups, uint32_t g0,
+__device__ __forceinline__ void cfft_f32_prefetching(float2 *__restrict__ data, float2 *lds, TW &twp, uint32_t ngroups, uint32_t g0,
                                                      uint32_t gstep)
 {
   using PL = Plan<LOGN>;
@@ -67,11 +80,12 @@ __device__ __forceinline__ void cfft_f32_prefetching(float2 *__restrict__ data, 
   };
   if (g0 < ngroups) fetch(v, g0, threadIdx.x);
   // vmcnt(0): the loop is entered with nothing in flight, so the waits at its top are derived from
-  // the back edge alone (16 loads, then 16 stores that may stay in flight into the next round)
+  // the back edge alone (16 loads, then the stores, which may stay in flight into the next round)
   __builtin_amdgcn_s_waitcnt(0x0F70);
   for (uint32_t g = g0; g < ngroups; g += gstep) {
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
+    twp.pin();
     float2 *__restrict__ p = data + (size_t)g * PL::N;
     float2 nx[16];
     // the last round re-reads its own transform instead of branching around the loads
@@ -83,7 +97,7 @@ __device__ __forceinline__ void cfft_f32_prefetching(float2 *__restrict__ data, 
       if (ORDER == 2) e = (int)(__brev((unsigned)e) >> (32 - LOGN));
       p[e] = x;
     };
-    fft_block_preloaded<PL, false>(v, lds, twr, tid, st, hook);
+    fft_block_preloaded<PL, false, Tune<LOGN>::HP>(v, lds, twp, tid, st, hook);
 #pragma unroll
     for (int i = 0; i < 16; i++) v[i] = nx[i];
     __syncthreads();  // the next transform's first LDS write must not overtake this one's last read
@@ -102,10 +116,12 @@ __global__ __launch_bounds__(Plan<LOGN>::T, Tune<LOGN>::MINW) void cfft_f32_kern
   twr.preload(threadIdx.x);
   const uint32_t g0 = blockIdx.x + blockIdx.y * gridDim.x, gstep = gridDim.x * gridDim.y;
   if constexpr (Tune<LOGN>::PRE) {
+    TwPow<PL, Tune<LOGN>::LAZYMASK> twp;
+    twp.preload(tw, threadIdx.x);
     // output order resolved once per launch, not per store: no branches between the stores
-    if (order == 0) cfft_f32_prefetching<LOGN, INV, 0>(data, lds, twr, ngroups, g0, gstep);
-    else if (order == 1) cfft_f32_prefetching<LOGN, INV, 1>(data, lds, twr, ngroups, g0, gstep);
-    else cfft_f32_prefetching<LOGN, INV, 2>(data, lds, twr, ngroups, g0, gstep);
+    if (order == 0) cfft_f32_prefetching<LOGN, INV, 0>(data, lds, twp, ngroups, g0, gstep);
+    else if (order == 1) cfft_f32_prefetching<LOGN, INV, 1>(data, lds, twp, ngroups, g0, gstep);
+    else cfft_f32_prefetching<LOGN, INV, 2>(data, lds, twp, ngroups, g0, gstep);
     return;
   }
   for (uint32_t g = g0; g < ngroups; g += gstep) {

@@ -113,6 +113,7 @@ __device__ __forceinline__ void butterfly<16>(float2 *v)
 // Plan<LOGN, TT>: TT threads per workgroup (0 = default: 256 below 4096 points, N/16 above).
 template <int LOGN_, int TT = 0>
 struct Plan {
+  static constexpr int E = 16;  // points per thread and pass
   static constexpr int LOGN = LOGN_;
   static constexpr int N = 1 << LOGN;
   static constexpr int NPASS = (LOGN + 3) / 4;
@@ -124,8 +125,8 @@ struct Plan {
   static constexpr int lns(int p) { return p == 0 ? 0 : lns(p - 1) + lr(p - 1); }
   // threads per workgroup and sequences per workgroup at 16 points per thread
   static constexpr int T = TT ? TT : ((N >= 4096) ? N / 16 : 256);
-  static constexpr int TPB = (T * 16) / N;
-  static_assert(TPB >= 1 && TPB * N == T * 16, "16 points per thread");
+  static constexpr int TPB = (T * E) / N;
+  static_assert(TPB >= 1 && TPB * N == T * E, "E points per thread");
   // LDS image: each sequence padded by 2 points per 16 (first-pass 16-byte stores and later
   // 8-byte reads conflict-free or 2-way) and skewed by 2 more points per sequence so that
   // accesses that walk ACROSS sequences (tile staging, transposes) spread over the banks.
@@ -151,7 +152,7 @@ struct Preloaded {
 template <class PL, class F>
 __device__ __forceinline__ void for_each_first_pass_input(int tid, F f)
 {
-  constexpr int LR = PL::lr(0), R = 1 << LR, NB = 16 / R, LNR = PL::LOGN - LR;
+  constexpr int LR = PL::lr(0), R = 1 << LR, NB = PL::E / R, LNR = PL::LOGN - LR;
 #pragma unroll
   for (int q = 0; q < NB; q++) {
     const int w = tid + q * PL::T;
@@ -161,10 +162,27 @@ __device__ __forceinline__ void for_each_first_pass_input(int tid, F f)
   }
 }
 
+// Same, with point e given as j + roff: roff = r * N/R is a compile-time constant per leg, so a
+// caller with a workgroup-uniform base pointer folds it into the (scalar) base and keeps a single
+// per-lane offset register for all 16 loads.
+template <class PL, class F>
+__device__ __forceinline__ void for_each_first_pass_input_split(int tid, F f)
+{
+  constexpr int LR = PL::lr(0), R = 1 << LR, NB = PL::E / R, LNR = PL::LOGN - LR;
+#pragma unroll
+  for (int q = 0; q < NB; q++) {
+    const int w = tid + q * PL::T;
+    const int t = w >> LNR, j = w & ((1 << LNR) - 1);
+#pragma unroll
+    for (int r = 0; r < R; r++) f(q * R + r, t, j, r << LNR);
+  }
+}
+
 // ---- twiddle sources ----
 // The pass code asks for twiddle `slot` (= q*(R-1) + r-1) of pass P, whose table index is idx.
 // TwTable reads the device-generated table (L1/L2-resident, never HBM in steady state).
 struct TwTable {
+  static constexpr bool lazy(int) { return false; }
   const float2 *__restrict__ tw;
   template <int P>
   __device__ __forceinline__ float2 get(int /*slot*/, int idx) const { return tw[idx]; }
@@ -175,15 +193,16 @@ struct TwTable {
 // transform it processes.  The other passes read the table.
 template <class PL, unsigned HMASK>
 struct TwRegs {
+  static constexpr bool lazy(int) { return false; }
   const float2 *__restrict__ tw;
-  float2 w[PL::NPASS][15];
+  float2 w[PL::NPASS][PL::E - 1];
 
   template <int P>
   __device__ __forceinline__ void preload_pass(int tid)
   {
     if constexpr (P < PL::NPASS) {
       if constexpr (P > 0 && ((HMASK >> P) & 1u)) {
-        constexpr int LOGN = PL::LOGN, LR = PL::lr(P), R = 1 << LR, NB = 16 / R, LNS = PL::lns(P), NS = 1 << LNS, LNR = LOGN - LR;
+        constexpr int LOGN = PL::LOGN, LR = PL::lr(P), R = 1 << LR, NB = PL::E / R, LNS = PL::lns(P), NS = 1 << LNS, LNR = LOGN - LR;
 #pragma unroll
         for (int q = 0; q < NB; q++) {
           const int j = (tid + q * PL::T) & ((1 << LNR) - 1);
@@ -207,6 +226,97 @@ struct TwRegs {
   }
 };
 
+// TwPow: the R-1 twiddles of one butterfly are the powers w, w^2 .. w^(R-1) of ONE number
+// w = W_N^stepk that depends only on the thread.  A persistent workgroup keeps w^1, w^2, w^4 (, w^8)
+// of every butterfly in registers (correctly rounded table values, loaded once per kernel) and
+// forms the other powers as products of at most three of them right where they are used: no
+// twiddle load, no twiddle address math and no outstanding vector-memory operation inside the
+// transform, which is what lets a prefetch of the NEXT transform stay in flight across all passes
+// (gfx9 counts loads and stores in one in-order vmcnt: waiting for a twiddle would wait for every
+// load issued before it).
+template <class PL, unsigned MASK = ~0u>
+struct TwPow {
+  // MASK: the passes served this way (bit p = pass p); the others read the table like TwTable.
+  static constexpr bool lazy(int p) { return (MASK >> p) & 1u; }
+  const float2 *__restrict__ tw;
+  template <int P>
+  __device__ __forceinline__ float2 get(int /*slot*/, int idx) const { return tw[idx]; }
+
+  static constexpr int nbase(int lr) { return lr; }
+  float2 b[PL::NPASS][PL::E / 2];  // [pass][butterfly q * nbase + i]
+
+  template <int P>
+  __device__ __forceinline__ void preload_pass(int tid)
+  {
+    if constexpr (P < PL::NPASS) {
+      if constexpr (P > 0 && lazy(P)) {
+        constexpr int LOGN = PL::LOGN, LR = PL::lr(P), R = 1 << LR, NB = PL::E / R, LNS = PL::lns(P), NS = 1 << LNS, LNR = LOGN - LR;
+        constexpr int NBASE = nbase(LR);
+        static_assert(NB * NBASE <= PL::E / 2, "TwPow: too many butterflies per thread for this radix");
+#pragma unroll
+        for (int q = 0; q < NB; q++) {
+          const int j = (tid + q * PL::T) & ((1 << LNR) - 1);
+          const int stepk = (j & (NS - 1)) << (LOGN - LNS - LR);
+#pragma unroll
+          for (int i = 0; i < NBASE; i++) b[P][q * NBASE + i] = tw[stepk << i];
+        }
+      }
+      preload_pass<P + 1>(tid);
+    }
+  }
+  __device__ __forceinline__ void preload(const float2 *__restrict__ table, int tid)
+  {
+    tw = table;
+    preload_pass<0>(tid);
+  }
+
+  // Call once per transform inside a persistent loop: makes the base values opaque to the
+  // optimiser, which would otherwise hoist every product out of the loop and hold all R-1
+  // twiddles of all passes in registers (spilling).
+  template <int P = 1>
+  __device__ __forceinline__ void pin()
+  {
+    if constexpr (P < PL::NPASS) {
+      constexpr int CNT = lazy(P) ? (PL::E >> PL::lr(P)) * nbase(PL::lr(P)) : 0;
+#pragma unroll
+      for (int i = 0; i < CNT; i++) asm volatile("" : "+v"(b[P][i].x), "+v"(b[P][i].y));
+      pin<P + 1>();
+    }
+  }
+
+  // v[r] *= w^r for the R legs of butterfly q of pass P
+  template <int P>
+  __device__ __forceinline__ void mul(int q, float2 *v) const
+  {
+    constexpr int LR = PL::lr(P);
+    const float2 *bq = &b[P][q * nbase(LR)];
+    float2 w[8];  // w[r], r < 8
+    w[1] = bq[0];
+    v[1] = cmul(v[1], w[1]);
+    if constexpr (LR >= 2) {
+      w[2] = bq[1];
+      w[3] = cmul(w[1], w[2]);
+      v[2] = cmul(v[2], w[2]);
+      v[3] = cmul(v[3], w[3]);
+    }
+    if constexpr (LR >= 3) {
+      w[4] = bq[2];
+      v[4] = cmul(v[4], w[4]);
+#pragma unroll
+      for (int r = 1; r < 4; r++) {
+        w[4 + r] = cmul(w[4], w[r]);
+        v[4 + r] = cmul(v[4 + r], w[4 + r]);
+      }
+    }
+    if constexpr (LR >= 4) {
+      const float2 w8 = bq[3];
+      v[8] = cmul(v[8], w8);
+#pragma unroll
+      for (int r = 1; r < 8; r++) v[8 + r] = cmul(v[8 + r], cmul(w8, w[r]));
+    }
+  }
+};
+
 // One pass.  P = pass index.  v holds the thread's 16 points: butterfly q (0..16/R-1), leg r at
 // v[q*R + r].
 // twc = this pass's twiddles (fetched during the previous pass), twn = filled with the next pass's
@@ -214,20 +324,21 @@ struct TwRegs {
 // registers, and their L1/L2 latency hides behind the barrier and the next gather instead of
 // stalling every pass (workgroups of 8192/16384-point transforms are too few per CU to hide it).
 //
-// hook() runs in the LAST pass between the twiddle multiplies and the butterflies: from there on this
-// transform no longer touches HBM until its stores, so a persistent kernel issues the next
-// transform's loads there -- ahead of this one's stores in the memory queues -- and their latency
-// and transfer overlap the last butterflies and the store drain.
+// hook() runs in pass HP between the twiddle multiplies and the butterflies.  A persistent kernel
+// issues the next transform's loads there -- ahead of this one's stores in the memory queues --
+// so that their latency and transfer overlap the remaining passes and the store drain.  With a
+// table twiddle source HP must be the last pass (a later twiddle wait would wait for the
+// prefetch too: one in-order vmcnt); with TwPow any pass works and the choice is register budget.
 struct NoHook {
   __device__ __forceinline__ void operator()() const {}
 };
 
-template <class PL, int P, bool LDS_IN, bool LDS_OUT, class TW, class Load, class Store, class Hook>
+template <class PL, int P, bool LDS_IN, bool LDS_OUT, int HP, class TW, class Load, class Store, class Hook>
 __device__ __forceinline__ void fft_pass(float2 *v, float2 *lds, const TW &tw, int tid, Load &ld, Store &st, const float2 *twc, float2 *twn,
                                          Hook &hook)
 {
   constexpr int LOGN = PL::LOGN, T = PL::T;
-  constexpr int LR = PL::lr(P), R = 1 << LR, NB = 16 / R;
+  constexpr int LR = PL::lr(P), R = 1 << LR, NB = PL::E / R;
   constexpr int LNS = PL::lns(P), NS = 1 << LNS;
   constexpr int LNR = LOGN - LR;  // log2(N/R): butterflies per transform
   constexpr bool FIRST = (P == 0), LAST = (P == PL::NPASS - 1);
@@ -248,14 +359,18 @@ __device__ __forceinline__ void fft_pass(float2 *v, float2 *lds, const TW &tw, i
     }
   }
   // ---- twiddle + butterfly ----
-  if (!FIRST) {
+  if constexpr (!FIRST) {
 #pragma unroll
     for (int q = 0; q < NB; q++) {
+      if constexpr (TW::lazy(P)) {
+        tw.template mul<P>(q, v + q * R);
+      } else {
 #pragma unroll
-      for (int r = 1; r < R; r++) v[q * R + r] = cmul(v[q * R + r], twc[q * (R - 1) + r - 1]);
+        for (int r = 1; r < R; r++) v[q * R + r] = cmul(v[q * R + r], twc[q * (R - 1) + r - 1]);
+      }
     }
   }
-  if constexpr (LAST && !std::is_same<Hook, NoHook>::value) {
+  if constexpr (P == HP && !std::is_same<Hook, NoHook>::value) {
     // twc is dead: the hook's registers take its place (and must not be scheduled any earlier)
     __builtin_amdgcn_sched_barrier(0);
     hook();
@@ -289,9 +404,9 @@ __device__ __forceinline__ void fft_pass(float2 *v, float2 *lds, const TW &tw, i
       for (int r = 0; r < R; r++) lds[base + PL::delta(r << LNS)] = v[q * R + r];
     }
   }
-  if constexpr (!LAST) {
+  if constexpr (!LAST && !TW::lazy(LAST ? P : P + 1)) {
     // next pass's twiddles: W_{NS*R}^{r k} = tw[r * k * N/(NS*R)], k = butterfly index mod NS
-    constexpr int LR1 = PL::lr(P + 1), R1 = 1 << LR1, NB1 = 16 / R1, LNS1 = PL::lns(P + 1), NS1 = 1 << LNS1, LNR1 = LOGN - LR1;
+    constexpr int LR1 = PL::lr(P + 1), R1 = 1 << LR1, NB1 = PL::E / R1, LNS1 = PL::lns(P + 1), NS1 = 1 << LNS1, LNR1 = LOGN - LR1;
 #pragma unroll
     for (int q = 0; q < NB1; q++) {
       const int j = (tid + q * T) & ((1 << LNR1) - 1);
@@ -299,17 +414,17 @@ __device__ __forceinline__ void fft_pass(float2 *v, float2 *lds, const TW &tw, i
 #pragma unroll
       for (int r = 1; r < R1; r++) twn[q * (R1 - 1) + r - 1] = tw.template get<P + 1>(q * (R1 - 1) + r - 1, r * stepk);
     }
-    __syncthreads();
   }
+  if constexpr (!LAST) __syncthreads();
 }
 
-template <class PL, int P, bool LDS_IN, bool LDS_OUT, class TW, class Load, class Store, class Hook>
+template <class PL, int P, bool LDS_IN, bool LDS_OUT, int HP, class TW, class Load, class Store, class Hook>
 struct PassLoop {
   static __device__ __forceinline__ void run(float2 *v, float2 *lds, const TW &tw, int tid, Load &ld, Store &st, float2 *twa, float2 *twb,
                                              Hook &hook)
   {
-    fft_pass<PL, P, LDS_IN, LDS_OUT>(v, lds, tw, tid, ld, st, twa, twb, hook);
-    if constexpr (P + 1 < PL::NPASS) PassLoop<PL, P + 1, LDS_IN, LDS_OUT, TW, Load, Store, Hook>::run(v, lds, tw, tid, ld, st, twb, twa, hook);
+    fft_pass<PL, P, LDS_IN, LDS_OUT, HP>(v, lds, tw, tid, ld, st, twa, twb, hook);
+    if constexpr (P + 1 < PL::NPASS) PassLoop<PL, P + 1, LDS_IN, LDS_OUT, HP, TW, Load, Store, Hook>::run(v, lds, tw, tid, ld, st, twb, twa, hook);
   }
 };
 
@@ -322,9 +437,9 @@ struct PassLoop {
 template <class PL, bool LDS_IN, bool LDS_OUT, class TW, class Load, class Store>
 __device__ __forceinline__ void fft_block_tw(float2 *lds, const TW &tw, int tid, Load ld, Store st)
 {
-  float2 v[16], twa[15], twb[15];
+  float2 v[PL::E], twa[PL::E - 1], twb[PL::E - 1];
   NoHook hook;
-  PassLoop<PL, 0, LDS_IN, LDS_OUT, TW, Load, Store, NoHook>::run(v, lds, tw, tid, ld, st, twa, twb, hook);
+  PassLoop<PL, 0, LDS_IN, LDS_OUT, -1, TW, Load, Store, NoHook>::run(v, lds, tw, tid, ld, st, twa, twb, hook);
 }
 
 template <class PL, bool LDS_IN, bool LDS_OUT, class Load, class Store>
@@ -334,13 +449,14 @@ __device__ __forceinline__ void fft_block(float2 *lds, const float2 *__restrict_
   fft_block_tw<PL, LDS_IN, LDS_OUT>(lds, t, tid, ld, st);
 }
 
-// Same with the first pass's inputs already in v[16] (see Preloaded); hook: see fft_pass.
-template <class PL, bool LDS_OUT, class TW, class Store, class Hook = NoHook>
+// Same with the first pass's inputs already in v[16] (see Preloaded); hook runs in pass HP
+// (default: the last), see fft_pass.
+template <class PL, bool LDS_OUT, int HP = PL::NPASS - 1, class TW, class Store, class Hook = NoHook>
 __device__ __forceinline__ void fft_block_preloaded(float2 *v, float2 *lds, const TW &tw, int tid, Store st, Hook hook = Hook())
 {
   Preloaded ld;
-  float2 twa[15], twb[15];
-  PassLoop<PL, 0, false, LDS_OUT, TW, Preloaded, Store, Hook>::run(v, lds, tw, tid, ld, st, twa, twb, hook);
+  float2 twa[PL::E - 1], twb[PL::E - 1];
+  PassLoop<PL, 0, false, LDS_OUT, HP, TW, Preloaded, Store, Hook>::run(v, lds, tw, tid, ld, st, twa, twb, hook);
 }
 
 }  // namespace armfft
