@@ -54,7 +54,7 @@ struct TuneBase {
 };
 template <int LOGN> struct Tune : TuneBase {};
 template <> struct Tune<11> : TuneBase { static constexpr unsigned HMASK = 6; static constexpr int MINW = 2, WGPCU = 2; };
-template <> struct Tune<12> : TuneBase { static constexpr unsigned HMASK = 6; static constexpr int MINW = 2, WGPCU = 2; };
+template <> struct Tune<12> : TuneBase { static constexpr unsigned LAZYMASK = ~0u; static constexpr int MINW = 2, WGPCU = 2, HP = 0; static constexpr bool PRE = true; };
 template <> struct Tune<13> : TuneBase { static constexpr unsigned LAZYMASK = ~0u; static constexpr int MINW = 2, WGPCU = 1, HP = 0; static constexpr bool PRE = true; };
 template <> struct Tune<14> : TuneBase { static constexpr int WGPCU = 1, HP = 3; static constexpr bool PRE = true; };
 
