@@ -50,33 +50,78 @@ __device__ __forceinline__ int scrambled_pos(int k)
 struct TuneBase {
   static constexpr unsigned HMASK = 0, LAZYMASK = 0;
   static constexpr int MINW = 4, WGPCU = 0, HP = 0;
-  static constexpr bool PRE = false;
+  static constexpr bool PRE = false, BUF = false, NESTED8 = false;
 };
 template <int LOGN> struct Tune : TuneBase {};
 template <> struct Tune<11> : TuneBase { static constexpr unsigned HMASK = 6; static constexpr int MINW = 2, WGPCU = 2; };
-template <> struct Tune<12> : TuneBase { static constexpr unsigned LAZYMASK = ~0u; static constexpr int MINW = 2, WGPCU = 2, HP = 0; static constexpr bool PRE = true; };
-template <> struct Tune<13> : TuneBase { static constexpr unsigned LAZYMASK = ~0u; static constexpr int MINW = 2, WGPCU = 1, HP = 0; static constexpr bool PRE = true; };
-template <> struct Tune<14> : TuneBase { static constexpr int WGPCU = 1, HP = 3; static constexpr bool PRE = true; };
+template <> struct Tune<12> : TuneBase { static constexpr unsigned LAZYMASK = ~0u; static constexpr int MINW = 2, WGPCU = 2, HP = 0; static constexpr bool PRE = true, BUF = true; };
+template <> struct Tune<13> : TuneBase { static constexpr unsigned LAZYMASK = ~0u; static constexpr int MINW = 2, WGPCU = 1, HP = 0; static constexpr bool PRE = true, BUF = true; };
+template <> struct Tune<14> : TuneBase { static constexpr unsigned LAZYMASK = 8; static constexpr int WGPCU = 1, HP = 2; static constexpr bool PRE = true, BUF = true, NESTED8 = true; };
 
 // Persistent workgroup that fetches its next transform while the current one is in flight
 // (Tune::PRE).  One transform per workgroup round (TPB == 1, g < ngroups == batch): no per-lane
 // guards and no branches between the memory instructions, so the compiler counts outstanding
 // loads and stores exactly and each wait covers only what it needs.
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// Buffer descriptor over one transform (gfx9 raw buffer: stride 0, range in bytes, 32-bit data
+// format): address = base + scalar offset + per-lane offset, so the 16 legs of a thread share ONE
+// per-lane offset register and differ only in a scalar -- no 64-bit address arithmetic in vector
+// registers (2 VALU + a register pair per global access otherwise).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t transform_rsrc(const float2 *base, uint32_t bytes)
+{
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(base), 0, (int)bytes, 0x00020000);
+}
+
+template <int LOGN, bool INV, int ORDER>
+struct BufferStore {
+  static constexpr bool SPLIT = true;
+  __amdgpu_buffer_rsrc_t rsrc;
+  float inv_n;
+  __device__ __forceinline__ void operator()(int, int e0, int roff, float2 x) const
+  {
+    if (INV) x = make_float2(x.x * inv_n, -x.y * inv_n);
+    u32x2 w;
+    w[0] = __float_as_uint(x.x);
+    w[1] = __float_as_uint(x.y);
+    if constexpr (ORDER == 0) {
+      __builtin_amdgcn_raw_buffer_store_b64(w, rsrc, e0 * 8, roff * 8, 0);
+    } else {
+      int e = e0 + roff;
+      if (ORDER == 1) e = scrambled_pos<LOGN>(e);
+      if (ORDER == 2) e = (int)(__brev((unsigned)e) >> (32 - LOGN));
+      __builtin_amdgcn_raw_buffer_store_b64(w, rsrc, e * 8, 0, 0);
+    }
+  }
+};
+
 template <int LOGN, bool INV, int ORDER, class TW>
 __device__ __forceinline__ void cfft_f32_prefetching(float2 *__restrict__ data, float2 *lds, TW &twp, uint32_t ngroups, uint32_t g0,
                                                      uint32_t gstep)
 {
   using PL = Plan<LOGN>;
   static_assert(PL::TPB == 1, "prefetching kernel: one transform per workgroup");
+  constexpr bool BUF = Tune<LOGN>::BUF;
+  constexpr uint32_t BYTES = PL::N * sizeof(float2);
   const float inv_n = 1.0f / (float)PL::N;
   float2 v[16];
   auto fetch = [&](float2 *dst, uint32_t g, int tid) {
     const float2 *__restrict__ p = data + (size_t)g * PL::N;
-    for_each_first_pass_input<PL>(tid, [&](int slot, int, int e) {
-      float2 x = p[e];
-      if (INV) x.y = -x.y;
-      dst[slot] = x;
-    });
+    if constexpr (BUF) {
+      const __amdgpu_buffer_rsrc_t rs = transform_rsrc(p, BYTES);
+      for_each_first_pass_input_split<PL>(tid, [&](int slot, int, int j, int roff) {
+        const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(rs, j * 8, roff * 8, 0);
+        float2 x = make_float2(__uint_as_float(w[0]), __uint_as_float(w[1]));
+        if (INV) x.y = -x.y;
+        dst[slot] = x;
+      });
+    } else {
+      for_each_first_pass_input<PL>(tid, [&](int slot, int, int e) {
+        float2 x = p[e];
+        if (INV) x.y = -x.y;
+        dst[slot] = x;
+      });
+    }
   };
   if (g0 < ngroups) fetch(v, g0, threadIdx.x);
   // vmcnt(0): the loop is entered with nothing in flight, so the waits at its top are derived from
@@ -91,13 +136,18 @@ __device__ __forceinline__ void cfft_f32_prefetching(float2 *__restrict__ data, 
     // the last round re-reads its own transform instead of branching around the loads
     const uint32_t gn = g + gstep < ngroups ? g + gstep : g;
     auto hook = [&]() { fetch(nx, gn, tid); };
-    auto st = [&](int, int e, float2 x) {
-      if (INV) x = make_float2(x.x * inv_n, -x.y * inv_n);
-      if (ORDER == 1) e = scrambled_pos<LOGN>(e);
-      if (ORDER == 2) e = (int)(__brev((unsigned)e) >> (32 - LOGN));
-      p[e] = x;
-    };
-    fft_block_preloaded<PL, false, Tune<LOGN>::HP>(v, lds, twp, tid, st, hook);
+    if constexpr (BUF) {
+      BufferStore<LOGN, INV, ORDER> st{transform_rsrc(p, BYTES), inv_n};
+      fft_block_preloaded<PL, false, Tune<LOGN>::HP>(v, lds, twp, tid, st, hook);
+    } else {
+      auto st = [&](int, int e, float2 x) {
+        if (INV) x = make_float2(x.x * inv_n, -x.y * inv_n);
+        if (ORDER == 1) e = scrambled_pos<LOGN>(e);
+        if (ORDER == 2) e = (int)(__brev((unsigned)e) >> (32 - LOGN));
+        p[e] = x;
+      };
+      fft_block_preloaded<PL, false, Tune<LOGN>::HP>(v, lds, twp, tid, st, hook);
+    }
 #pragma unroll
     for (int i = 0; i < 16; i++) v[i] = nx[i];
     __syncthreads();  // the next transform's first LDS write must not overtake this one's last read
@@ -116,7 +166,7 @@ __global__ __launch_bounds__(Plan<LOGN>::T, Tune<LOGN>::MINW) void cfft_f32_kern
   twr.preload(threadIdx.x);
   const uint32_t g0 = blockIdx.x + blockIdx.y * gridDim.x, gstep = gridDim.x * gridDim.y;
   if constexpr (Tune<LOGN>::PRE) {
-    TwPow<PL, Tune<LOGN>::LAZYMASK> twp;
+    TwPow<PL, Tune<LOGN>::LAZYMASK, Tune<LOGN>::NESTED8> twp;
     twp.preload(tw, threadIdx.x);
     // output order resolved once per launch, not per store: no branches between the stores
     if (order == 0) cfft_f32_prefetching<LOGN, INV, 0>(data, lds, twp, ngroups, g0, gstep);

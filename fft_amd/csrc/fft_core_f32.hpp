@@ -234,8 +234,11 @@ struct TwRegs {
 // transform, which is what lets a prefetch of the NEXT transform stay in flight across all passes
 // (gfx9 counts loads and stores in one in-order vmcnt: waiting for a twiddle would wait for every
 // load issued before it).
-template <class PL, unsigned MASK = ~0u>
+template <class PL, unsigned MASK = ~0u, bool NESTED8 = false>
 struct TwPow {
+  // NESTED8: radix-8 passes multiply the data by w^1, w^2, w^4 directly (v5 = (v5 w1) w4 ...):
+  // 12 complex multiplies instead of 11 and the same number of roundings, but no product
+  // temporaries at all -- for kernels at the edge of their register budget.
   // MASK: the passes served this way (bit p = pass p); the others read the table like TwTable.
   static constexpr bool lazy(int p) { return (MASK >> p) & 1u; }
   const float2 *__restrict__ tw;
@@ -290,6 +293,15 @@ struct TwPow {
   {
     constexpr int LR = PL::lr(P);
     const float2 *bq = &b[P][q * nbase(LR)];
+    if constexpr (NESTED8 && LR == 3) {
+#pragma unroll
+      for (int r = 1; r < 8; r++) {
+        if (r & 1) v[r] = cmul(v[r], bq[0]);
+        if (r & 2) v[r] = cmul(v[r], bq[1]);
+        if (r & 4) v[r] = cmul(v[r], bq[2]);
+      }
+      return;
+    }
     float2 w[8];  // w[r], r < 8
     w[1] = bq[0];
     v[1] = cmul(v[1], w[1]);
@@ -329,6 +341,14 @@ struct TwPow {
 // so that their latency and transfer overlap the remaining passes and the store drain.  With a
 // table twiddle source HP must be the last pass (a later twiddle wait would wait for the
 // prefetch too: one in-order vmcnt); with TwPow any pass works and the choice is register budget.
+// A Store functor that declares `static constexpr bool SPLIT = true` receives output bin e as
+// (e0, roff) with roff = r * Ns a compile-time constant per leg (st(t, e0, roff, val)): a caller
+// with a workgroup-uniform base folds roff into a scalar offset (buffer stores).
+template <class S, class = void>
+struct store_is_split : std::false_type {};
+template <class S>
+struct store_is_split<S, std::void_t<decltype(S::SPLIT)>> : std::true_type {};
+
 struct NoHook {
   __device__ __forceinline__ void operator()() const {}
 };
@@ -389,7 +409,10 @@ __device__ __forceinline__ void fft_pass(float2 *v, float2 *lds, const TW &tw, i
     const int j0 = ((j >> LNS) << (LNS + LR)) + k;
     if (LAST) {
 #pragma unroll
-      for (int r = 0; r < R; r++) st(t, j0 + (r << LNS), v[q * R + r]);
+      for (int r = 0; r < R; r++) {
+        if constexpr (store_is_split<Store>::value) st(t, j0, r << LNS, v[q * R + r]);
+        else st(t, j0 + (r << LNS), v[q * R + r]);
+      }
     } else if (FIRST && R >= 2) {
       // NS == 1: R consecutive points per butterfly -> 16-byte LDS stores
       const int base = PL::idx(t, j * R);
