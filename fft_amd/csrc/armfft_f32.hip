@@ -201,14 +201,139 @@ __global__ __launch_bounds__(Plan<LOGN>::T, Tune<LOGN>::MINW) void cfft_f32_kern
 // LOGM = log2(N/2).  Forward: z = FFT(x as N/2 complex) to LDS, then the split of stage_rfft_f32
 // (arm_rfft_fast_f32.c:316-402).  Inverse: merge_rfft_f32 (:405-462) fused into the load of the
 // inverse complex FFT.
+// Per-size tuning of the real-FFT kernel (LOGM = log2 of the complex length N/2): sizes whose
+// workgroup holds exactly one transform run persistent, prefetching workgroups like the complex
+// kernel (TwPow twiddles, buffer addressing), with the thread-constant split/merge factors kept
+// in registers across transforms.
+template <int LOGM> struct RTune { static constexpr int MINW = 4, WGPCU = 0; static constexpr bool NESTED8 = false; };
+template <> struct RTune<12> { static constexpr int MINW = 2, WGPCU = 2; static constexpr bool NESTED8 = false; };
+template <> struct RTune<13> { static constexpr int MINW = 2, WGPCU = 1; static constexpr bool NESTED8 = true; };
+
 template <int LOGM, bool INV>
-__global__ __launch_bounds__(Plan<LOGM>::T, 4) void rfft_f32_kernel(const float2 *__restrict__ in, float2 *__restrict__ out,
+__device__ __forceinline__ void rfft_f32_prefetching(const float2 *__restrict__ in, float2 *__restrict__ out, float2 *lds,
+                                                     const float2 *__restrict__ tw, const float2 *__restrict__ twr, uint32_t ngroups,
+                                                     uint32_t g0, uint32_t gstep)
+{
+  using PL = Plan<LOGM>;
+  static_assert(PL::TPB == 1, "prefetching kernel: one transform per workgroup");
+  constexpr int M = PL::N;
+  constexpr uint32_t BYTES = M * sizeof(float2);
+  TwPow<PL, ~0u, RTune<LOGM>::NESTED8> twp;
+  twp.preload(tw, threadIdx.x);
+  auto load2 = [](const __amdgpu_buffer_rsrc_t &rs, int voff, int soff) -> float2 {
+    const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
+    return make_float2(__uint_as_float(w[0]), __uint_as_float(w[1]));
+  };
+  if constexpr (!INV) {
+    // split factors (sin, cos) of the 16 bins this thread's last pass produces: the thread splits
+    // exactly those, so its own Z[k] never leaves its registers and only Z[M-k] comes from LDS
+    float2 csr[16];
+    for_each_last_pass_output<PL>(threadIdx.x, [&](int slot, int, int e0, int roff) { csr[slot] = twr[e0 + roff]; });
+    auto fetch = [&](float2 *dst, uint32_t g, int tid) {
+      const __amdgpu_buffer_rsrc_t rs = transform_rsrc(in + (size_t)g * M, BYTES);
+      for_each_first_pass_input_split<PL>(tid, [&](int slot, int, int j, int roff) { dst[slot] = load2(rs, j * 8, roff * 8); });
+    };
+    float2 v[16];
+    if (g0 < ngroups) fetch(v, g0, threadIdx.x);
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // see cfft_f32_prefetching
+    for (uint32_t g = g0; g < ngroups; g += gstep) {
+      int tid = threadIdx.x;
+      asm volatile("" : "+v"(tid));
+      twp.pin();
+      float2 nx[16];
+      const uint32_t gn = g + gstep < ngroups ? g + gstep : g;
+      auto hook = [&]() { fetch(nx, gn, tid); };
+      auto st = [&](int t, int e, float2 x) { lds[PL::idx(t, e)] = x; };
+      fft_block_preloaded<PL, true, 0>(v, lds, twp, tid, st, hook);
+      __syncthreads();
+      // split: bin k from Z[k] (still in v[]) and Z[M-k]
+      const __amdgpu_buffer_rsrc_t ro = transform_rsrc(out + (size_t)g * M, BYTES);
+      for_each_last_pass_output<PL>(tid, [&](int slot, int, int e0, int roff) {
+        const int k = e0 + roff;
+        const float2 A = v[slot];
+        const float2 B = lds[PL::idx(0, (M - k) & (M - 1))];
+        const float2 c = csr[slot];  // (sin, cos)
+        const float a = B.x - A.x, b = B.y + A.y;
+        float2 o;
+        o.x = 0.5f * (A.x + B.x + c.x * a + c.y * b);
+        o.y = 0.5f * (A.y - B.y + c.y * a - c.x * b);
+        if (k == 0) o = make_float2(A.x + A.y, A.x - A.y);  // 0.5*((2 re) +- (2 im)), exact
+        u32x2 w;
+        w[0] = __float_as_uint(o.x);
+        w[1] = __float_as_uint(o.y);
+        __builtin_amdgcn_raw_buffer_store_b64(w, ro, e0 * 8, roff * 8, 0);
+        // four bins at a time: hoisting all 16 LDS reads costs more registers than the kernel has
+        if ((slot & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      });
+#pragma unroll
+      for (int i = 0; i < 16; i++) v[i] = nx[i];
+      __syncthreads();  // the next transform's first LDS write must not overtake the split's reads
+    }
+  } else {
+    // merge factors of this thread's 16 first-pass inputs e = j + roff, and the mirrored bins'
+    // per-lane offset: (M - e) * 8 = (M - j - 15 S) * 8 + (15 - r) S * 8 with S = M / 16 (first pass
+    // radix 16: TPB == 1 implies LOGM >= 12), always >= 0; e == 0 reads one element past the end,
+    // which a buffer load returns as zero and the e == 0 branch does not use
+    static_assert(PL::lr(0) == 4, "first pass of radix 16");
+    constexpr int S = M / 16;
+    float2 cm[16];
+    for_each_first_pass_input_split<PL>(threadIdx.x, [&](int slot, int, int j, int roff) { cm[slot] = twr[j + roff]; });
+    auto fetch = [&](float2 *a, float2 *b, uint32_t g, int tid) {
+      const __amdgpu_buffer_rsrc_t rs = transform_rsrc(in + (size_t)g * M, BYTES);
+      for_each_first_pass_input_split<PL>(tid, [&](int slot, int, int j, int roff) {
+        a[slot] = load2(rs, j * 8, roff * 8);
+        b[slot] = load2(rs, (M - j - 15 * S) * 8, (15 * S - roff) * 8);
+      });
+    };
+    float2 A[16], B[16];
+    if (g0 < ngroups) fetch(A, B, g0, threadIdx.x);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    const float inv_m = 1.0f / (float)M;
+    for (uint32_t g = g0; g < ngroups; g += gstep) {
+      int tid = threadIdx.x;
+      asm volatile("" : "+v"(tid));
+      twp.pin();
+      float2 v[16];
+      for_each_first_pass_input_split<PL>(tid, [&](int slot, int, int j, int roff) {
+        const float2 a2 = A[slot], b2 = B[slot], c = cm[slot];
+        float2 o;
+        if ((j | roff) == 0) {
+          o = make_float2(0.5f * (a2.x + a2.y), 0.5f * (a2.x - a2.y));
+        } else {
+          const float a = a2.x - b2.x, b = a2.y + b2.y;
+          o.x = 0.5f * (a2.x + b2.x - c.x * a - c.y * b);
+          o.y = 0.5f * (a2.y - b2.y + c.y * a - c.x * b);
+        }
+        o.y = -o.y;  // conjugate in (inverse through the forward kernel)
+        v[slot] = o;
+      });
+      float2 nA[16], nB[16];
+      const uint32_t gn = g + gstep < ngroups ? g + gstep : g;
+      auto hook = [&]() { fetch(nA, nB, gn, tid); };
+      BufferStore<LOGM, true, 0> st{transform_rsrc(out + (size_t)g * M, BYTES), inv_m};
+      fft_block_preloaded<PL, false, 0>(v, lds, twp, tid, st, hook);
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        A[i] = nA[i];
+        B[i] = nB[i];
+      }
+      __syncthreads();
+    }
+  }
+}
+
+template <int LOGM, bool INV>
+__global__ __launch_bounds__(Plan<LOGM>::T, RTune<LOGM>::MINW) void rfft_f32_kernel(const float2 *__restrict__ in, float2 *__restrict__ out,
                                                                  const float2 *__restrict__ tw, const float2 *__restrict__ twr,
                                                                  uint32_t batch, uint32_t ngroups)
 {
   using PL = Plan<LOGM>;
   constexpr int M = PL::N;
   extern __shared__ __attribute__((aligned(16))) float2 lds[];
+  if constexpr (RTune<LOGM>::WGPCU > 0) {
+    rfft_f32_prefetching<LOGM, INV>(in, out, lds, tw, twr, ngroups, blockIdx.x + blockIdx.y * gridDim.x, gridDim.x * gridDim.y);
+    return;
+  }
   const int tid = threadIdx.x;
   {
     const uint32_t g = blockIdx.x + blockIdx.y * gridDim.x;
@@ -377,7 +502,12 @@ static hipError_t launch_rfft_one(const float2 *in, float2 *out, const float2 *t
     attr_done[dev] = true;
   }
   const uint32_t ngroups = (batch + PL::TPB - 1) / PL::TPB;
-  kern<<<grid_for(ngroups), PL::T, PL::LDS_BYTES, stream>>>(in, out, tw, twr, batch, ngroups);
+  dim3 grid = grid_for(ngroups);
+  if (RTune<LOGM>::WGPCU) {
+    const uint32_t resident = (uint32_t)RTune<LOGM>::WGPCU * (uint32_t)cu_count(dev);
+    if (ngroups > resident) grid = dim3(resident, 1, 1);
+  }
+  kern<<<grid, PL::T, PL::LDS_BYTES, stream>>>(in, out, tw, twr, batch, ngroups);
   return hipGetLastError();
 }
 

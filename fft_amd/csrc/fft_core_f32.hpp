@@ -178,6 +178,22 @@ __device__ __forceinline__ void for_each_first_pass_input_split(int tid, F f)
   }
 }
 
+// Calls f(slot, t, e0, roff) for the 16 last-pass outputs of thread tid: after the transform,
+// v[slot] holds output bin e0 + roff of sequence t (roff = r * Ns: compile-time constant per leg).
+template <class PL, class F>
+__device__ __forceinline__ void for_each_last_pass_output(int tid, F f)
+{
+  constexpr int P = PL::NPASS - 1, LR = PL::lr(P), R = 1 << LR, NB = PL::E / R, LNS = PL::lns(P), NS = 1 << LNS, LNR = PL::LOGN - LR;
+#pragma unroll
+  for (int q = 0; q < NB; q++) {
+    const int w = tid + q * PL::T;
+    const int t = w >> LNR, j = w & ((1 << LNR) - 1);
+    const int j0 = ((j >> LNS) << (LNS + LR)) + (j & (NS - 1));
+#pragma unroll
+    for (int r = 0; r < R; r++) f(q * R + r, t, j0, r << LNS);
+  }
+}
+
 // ---- twiddle sources ----
 // The pass code asks for twiddle `slot` (= q*(R-1) + r-1) of pass P, whose table index is idx.
 // TwTable reads the device-generated table (L1/L2-resident, never HBM in steady state).
