@@ -39,6 +39,8 @@ __constant__ int8_t k_g2_taps[37][2] = {
 constexpr int kCodeLen = 1023;
 
 // one sequence per workgroup at every size: N/16 threads
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
 template <int LOGN>
 using GPlan = Plan<LOGN, (1 << LOGN) / 16>;
 
@@ -397,19 +399,30 @@ __global__ __launch_bounds__(GPlan<LOGN>::T, GPlan<LOGN>::T >= 1024 ? 4 : 3) voi
   __syncthreads();
 
   const float inv_n = 1.0f / (float)N;
+  // twiddles of the per-PRN transforms: powers of thread-constant bases held in registers for the
+  // whole PRN loop (TwPow), no twiddle loads or address math per transform
+  // (up to 4096 points; the larger sizes are register-bound and keep the table)
+  typename std::conditional<(LOGN <= 12), TwPow<PL>, TwTable>::type twp;
+  twp.preload(tw, tid);
   for (int p = 0; p < n_prn; p++) {
     int lt = tid;
-    asm volatile("" : "+v"(lt));  // per-thread twiddle/LDS address math stays inside the loop (else: spills)
-    const float2 *__restrict__ cs = spectra + (size_t)p * N;
+    asm volatile("" : "+v"(lt));  // per-thread LDS address math stays inside the loop (else: spills)
+    twp.pin();
+    // the PRN's spectrum through a buffer descriptor: one per-lane offset register for the 16
+    // legs, scalar leg offsets, no 64-bit address arithmetic in vector registers
+    const __amdgpu_buffer_rsrc_t cs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(spectra + (size_t)p * N), 0, (int)(N * sizeof(float2)), 0x00020000);
     // IFFT(Z conj(C)) = conj(FFT(conj(Z) C)) / N; only the magnitude is used
     float2 v[16];
-    for_each_first_pass_input<PL>(lt, [&](int slot, int, int e) { v[slot] = cmul(zc[slot], cs[e]); });
+    for_each_first_pass_input_split<PL>(lt, [&](int slot, int, int j, int roff) {
+      const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(cs, j * 8, roff * 8, 0);
+      v[slot] = cmul(zc[slot], make_float2(__uint_as_float(w[0]), __uint_as_float(w[1])));
+    });
     auto st = [&](int, int k, float2 y) {
       const float re = y.x * inv_n, im = y.y * inv_n;
       magl[mag_idx(k)] = sqrtf(re * re + im * im);
     };
-    TwTable twt{tw};
-    fft_block_preloaded<PL, true>(v, lds, twt, lt, st);
+    fft_block_preloaded<PL, true>(v, lds, twp, lt, st);
     __syncthreads();
     auto mag = [&](int m) -> float { return magl[mag_idx(m)]; };
     const Top2 t = top2_scan<T, 16, true>(mag, N, sep, lt, xch);

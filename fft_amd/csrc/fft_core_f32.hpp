@@ -200,6 +200,9 @@ __device__ __forceinline__ void for_each_last_pass_output(int tid, F f)
 struct TwTable {
   static constexpr bool lazy(int) { return false; }
   const float2 *__restrict__ tw;
+  // same set-up interface as TwPow, so that a kernel can pick its twiddle source per size
+  __device__ __forceinline__ void preload(const float2 *__restrict__ table, int) { tw = table; }
+  __device__ __forceinline__ void pin() {}
   template <int P>
   __device__ __forceinline__ float2 get(int /*slot*/, int idx) const { return tw[idx]; }
 };
