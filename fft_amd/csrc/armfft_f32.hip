@@ -205,16 +205,22 @@ __global__ __launch_bounds__(Plan<LOGN>::T, Tune<LOGN>::MINW) void cfft_f32_kern
 // workgroup holds exactly one transform run persistent, prefetching workgroups like the complex
 // kernel (TwPow twiddles, buffer addressing), with the thread-constant split/merge factors kept
 // in registers across transforms.
+// 1024 and 2048 complex points: small workgroups of one transform each (64 / 128 threads) so that
+// the same persistent structure applies; 8 / 4 of them per CU.
 template <int LOGM> struct RTune { static constexpr int MINW = 4, WGPCU = 0; static constexpr bool NESTED8 = false; };
+template <> struct RTune<10> { static constexpr int MINW = 2, WGPCU = 8; static constexpr bool NESTED8 = false; };
+template <> struct RTune<11> { static constexpr int MINW = 2, WGPCU = 4; static constexpr bool NESTED8 = false; };
 template <> struct RTune<12> { static constexpr int MINW = 2, WGPCU = 2; static constexpr bool NESTED8 = false; };
 template <> struct RTune<13> { static constexpr int MINW = 2, WGPCU = 1; static constexpr bool NESTED8 = true; };
+
+template <int LOGM> using RPlan = Plan<LOGM, (LOGM == 10 || LOGM == 11) ? (1 << LOGM) / 16 : 0>;
 
 template <int LOGM, bool INV>
 __device__ __forceinline__ void rfft_f32_prefetching(const float2 *__restrict__ in, float2 *__restrict__ out, float2 *lds,
                                                      const float2 *__restrict__ tw, const float2 *__restrict__ twr, uint32_t ngroups,
                                                      uint32_t g0, uint32_t gstep)
 {
-  using PL = Plan<LOGM>;
+  using PL = RPlan<LOGM>;
   static_assert(PL::TPB == 1, "prefetching kernel: one transform per workgroup");
   constexpr int M = PL::N;
   constexpr uint32_t BYTES = M * sizeof(float2);
@@ -323,11 +329,11 @@ __device__ __forceinline__ void rfft_f32_prefetching(const float2 *__restrict__ 
 }
 
 template <int LOGM, bool INV>
-__global__ __launch_bounds__(Plan<LOGM>::T, RTune<LOGM>::MINW) void rfft_f32_kernel(const float2 *__restrict__ in, float2 *__restrict__ out,
+__global__ __launch_bounds__(RPlan<LOGM>::T, RTune<LOGM>::MINW) void rfft_f32_kernel(const float2 *__restrict__ in, float2 *__restrict__ out,
                                                                  const float2 *__restrict__ tw, const float2 *__restrict__ twr,
                                                                  uint32_t batch, uint32_t ngroups)
 {
-  using PL = Plan<LOGM>;
+  using PL = RPlan<LOGM>;
   constexpr int M = PL::N;
   extern __shared__ __attribute__((aligned(16))) float2 lds[];
   if constexpr (RTune<LOGM>::WGPCU > 0) {
@@ -491,7 +497,7 @@ template <int LOGM, bool INV>
 static hipError_t launch_rfft_one(const float2 *in, float2 *out, const float2 *tw, const float2 *twr, uint32_t batch,
                                   hipStream_t stream)
 {
-  using PL = Plan<LOGM>;
+  using PL = RPlan<LOGM>;
   static bool attr_done[16] = {false};
   int dev = 0;
   (void)hipGetDevice(&dev);
