@@ -174,6 +174,40 @@ __global__ __launch_bounds__(Plan<LOGN>::T, Tune<LOGN>::MINW) void cfft_f32_kern
     else cfft_f32_prefetching<LOGN, INV, 2>(data, lds, twp, ngroups, g0, gstep);
     return;
   }
+  if constexpr (LOGN <= 5) {
+    // 16 and 32 points: a thread's first-pass legs are 8 bytes at a 128/256-byte stride across
+    // lanes, so the workgroup's transforms (one contiguous 32 KiB block) are staged through LDS
+    // with 16-byte coalesced accesses instead, in and out
+    const uint32_t g = g0;
+    if (g >= ngroups) return;
+    const int tid = threadIdx.x;
+    const uint32_t t0 = g * PL::TPB;
+    const uint32_t nvalid = (batch - t0 >= (uint32_t)PL::TPB ? (uint32_t)PL::TPB : batch - t0) * PL::N;  // points
+    float2 *__restrict__ p = data + (size_t)t0 * PL::N;
+    constexpr int PAIRS = PL::TPB * PL::N / 2;
+    for (int i = tid; i < PAIRS; i += PL::T) {
+      const int e2 = 2 * i, t = e2 >> LOGN, e = e2 & (PL::N - 1);
+      float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+      if ((uint32_t)e2 < nvalid) x = *reinterpret_cast<const float4 *>(p + e2);
+      if (INV) { x.y = -x.y; x.w = -x.w; }
+      *reinterpret_cast<float4 *>(&lds[PL::idx(t, e)]) = x;
+    }
+    __syncthreads();
+    auto ld = [&](int t, int e) -> float2 { return lds[PL::idx(t, e)]; };
+    auto st = [&](int t, int e, float2 v) {
+      if (INV) v = make_float2(v.x * inv_n, -v.y * inv_n);
+      if (order == 1) e = scrambled_pos<LOGN>(e);
+      if (order == 2) e = (int)(__brev((unsigned)e) >> (32 - LOGN));
+      lds[PL::idx(t, e)] = v;
+    };
+    fft_block_tw<PL, true, true>(lds, twr, tid, ld, st);
+    __syncthreads();
+    for (int i = tid; i < PAIRS; i += PL::T) {
+      const int e2 = 2 * i, t = e2 >> LOGN, e = e2 & (PL::N - 1);
+      if ((uint32_t)e2 < nvalid) *reinterpret_cast<float4 *>(p + e2) = *reinterpret_cast<const float4 *>(&lds[PL::idx(t, e)]);
+    }
+    return;
+  }
   for (uint32_t g = g0; g < ngroups; g += gstep) {
     int tid = threadIdx.x;
     if (Tune<LOGN>::WGPCU) asm volatile("" : "+v"(tid));  // keep per-thread address math inside the loop
