@@ -791,9 +791,9 @@ arm_status arm_cfft_u32_f32_dev(const arm_cfft_instance_u32_f32 *S, float32_t *p
   if (l < kMinLargeLog || l > kMaxLargeLog) { set_error("arm_cfft_u32_f32_dev: unsupported fftLen %u", S->fftLen); return ARM_MATH_ARGUMENT_ERROR; }
   if (!work || work == p) { set_error("arm_cfft_u32_f32_dev: a separate workspace of batch*fftLen*8 bytes is required"); return ARM_MATH_ARGUMENT_ERROR; }
   const int l2 = l / 2, l1 = l - l2;
-  const float2 *tw1 = dev_tw_f32(l1), *tw2 = dev_tw_f32(l2), *lo = dev_tw_lo(l), *hi = dev_tw_f32(l - 10);
-  if (!tw1 || !tw2 || !lo || !hi) return ARM_MATH_ARGUMENT_ERROR;
-  hipError_t e = launch_cfft_large_f32(l, reinterpret_cast<float2 *>(p), reinterpret_cast<float2 *>(work), tw1, tw2, lo, hi, batch,
+  const float2 *tw1 = dev_tw_f32(l1), *tw2 = dev_tw_f32(l2), *big = dev_tw_lo(l);
+  if (!tw1 || !tw2 || !big) return ARM_MATH_ARGUMENT_ERROR;
+  hipError_t e = launch_cfft_large_f32(l, reinterpret_cast<float2 *>(p), reinterpret_cast<float2 *>(work), tw1, tw2, big, batch,
                                        ifft != 0, (hipStream_t)stream);
   return hip_ok(e, "cfft_large_f32 launch") ? ARM_MATH_SUCCESS : ARM_MATH_ARGUMENT_ERROR;
 }

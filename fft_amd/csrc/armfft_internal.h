@@ -43,8 +43,9 @@ hipError_t launch_rfft_q31(int logn_real, const int32_t *in, int32_t *out, const
 
 // large complex f32 (2^15..2^22), four-step: data -> work -> data
 hipError_t launch_cfft_large_f32(int logn, float2 *data, float2 *work, const float2 *tw1, const float2 *tw2,
-                                 const float2 *tw_lo, const float2 *tw_hi, uint32_t batch, bool inverse, hipStream_t stream);
-hipError_t launch_gen_twiddle_lo(float2 *tw, int logn, hipStream_t stream);  // exp(-2 pi i m / 2^logn), m < 1024
+                                 const float2 *tw_big, uint32_t batch, bool inverse, hipStream_t stream);
+// three-level table of W_N, N = 2^logn, into a buffer of 1024 entries (layout: armfft_large.hip)
+hipError_t launch_gen_twiddle_lo(float2 *tw, int logn, hipStream_t stream);
 
 // on-device table generation
 hipError_t launch_gen_twiddle_f32(float2 *tw, uint32_t n, hipStream_t stream);        // exp(-2 pi i m/n), m < n

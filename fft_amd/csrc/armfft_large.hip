@@ -21,7 +21,63 @@
 
 namespace armfft {
 
-constexpr int kLoLog = 10;  // W_N^m = lo[m & 1023] * hi[m >> 10]: two correctly rounded tables; lo (8 KiB) lives in LDS
+// Big twiddle W_N^m, m < N <= 2^22, as the product of three correctly rounded table entries,
+//   W_N^m = a[m & 127] * b[(m >> 7) & 127] * c[m >> 14]      (a: W_N^i, b: W_N^(128 i), c: W_N^(16384 i)),
+// 128 + 128 + 256 entries = 4 KiB, copied to LDS by every pass-1 workgroup: the lookups are LDS
+// reads (lgkmcnt), so nothing in the transform's store path touches vector memory and the
+// prefetch of the next tile survives until the loop top (see the kernel comment).  The table
+// buffer keeps its historical size of 1 << kLoLog entries.
+constexpr int kLoLog = 10;
+constexpr int kBigA = 0, kBigB = 128, kBigC = 256, kBigEntries = 512;
+
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t xform_rsrc(const float2 *base, size_t n_points)
+{
+  // gfx9 raw buffer: stride 0, range in bytes, 32-bit data format (<= 32 MiB per transform here)
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(base), 0, (int)(n_points * sizeof(float2)), 0x00020000);
+}
+__device__ __forceinline__ float2 buf_load(const __amdgpu_buffer_rsrc_t &rs, uint32_t voff, uint32_t soff)
+{
+  const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)voff, (int)soff, 0);
+  return make_float2(__uint_as_float(w[0]), __uint_as_float(w[1]));
+}
+__device__ __forceinline__ void buf_store(const __amdgpu_buffer_rsrc_t &rs, uint32_t voff, uint32_t soff, float2 x)
+{
+  u32x2 w;
+  w[0] = __float_as_uint(x.x);
+  w[1] = __float_as_uint(x.y);
+  __builtin_amdgcn_raw_buffer_store_b64(w, rs, (int)voff, (int)soff, 0);
+}
+
+// MODE 1 store: output bin k = e0 + roff of sequence seq is multiplied by W_N^(seq k) and written
+// to the intermediate B[seq][k].  Layout of B: row-major (rows of 2^LOGA points), or -- `tiled` --
+// the order in which pass 2 consumes it: blocks of C2 = 16384 / n_seq adjacent columns k, each
+// block holding its rows one after the other ([k / C2][seq][k % C2], 16384 points = 128 KiB per
+// block).  Pass 2 then reads each of its tiles as ONE contiguous block instead of n_seq runs of
+// C2 * 8 = 64 bytes; this pass writes runs of C * C2 * 8 = 512 bytes instead of whole rows.  The
+// leg offset roff = r * Ns is a multiple of C2 whenever the launcher selects `tiled`, so it still
+// folds into the scalar offset: (k / C2) * 16384 = (e0 / C2) * 16384 + roff * n_seq.
+template <int LOGA, bool TILED>
+struct RowStore {
+  static constexpr bool SPLIT = true;
+  __amdgpu_buffer_rsrc_t rs;
+  const float2 *big;
+  uint32_t c0;
+  int log_seq;   // log2 of the number of sequences (rows of B)
+  __device__ __forceinline__ void operator()(int t, int e0, int roff, float2 v) const
+  {
+    const uint32_t seq = c0 + (uint32_t)t;
+    const uint32_t m = seq * (uint32_t)(e0 + roff);  // < N
+    const float2 w = cmul(cmul(big[kBigA + (m & 127u)], big[kBigB + ((m >> 7) & 127u)]), big[kBigC + (m >> 14)]);
+    const int lc2 = 14 - log_seq;
+    const uint32_t row_major = (seq << LOGA) + (uint32_t)e0;
+    const uint32_t blocked = (((uint32_t)e0 >> lc2) << 14) + (seq << lc2) + ((uint32_t)e0 & ((1u << lc2) - 1u));
+    const uint32_t voff = (TILED ? blocked : row_major) * 8u;
+    const uint32_t soff = (TILED ? (uint32_t)roff << log_seq : (uint32_t)roff) * 8u;
+    buf_store(rs, voff, soff, cmul(v, w));
+  }
+};
 
 // MODE 1: tile in -> FFT -> * W_N^(seq * k) -> rows out.   MODE 2: tile in -> FFT -> tile out.
 // Persistent workgroups, (a) XCD-aware: workgroups are dispatched round-robin over the 8 XCDs
@@ -31,18 +87,26 @@ constexpr int kLoLog = 10;  // W_N^m = lo[m & 1023] * hi[m >> 10]: two correctly
 // pair (2q, 2q+1) in the same iteration: the second reader and the second writer of a line find it
 // in that XCD's L2.  (b) The next tile's 16 loads per thread are in flight (in registers) while
 // the current tile is transformed: with 145 KiB of LDS only one workgroup fits a CU, so without
-// this the memory system idles during every FFT.
-template <int LOGA, int MODE, bool INV>
+// this the memory system idles during every FFT.  gfx9 counts loads and stores in one in-order
+// vmcnt, so a prefetch survives only until the next wait on ANY later vector-memory access: the
+// loads are issued in the second-to-last pass (after its table twiddles have been consumed), the
+// last pass takes its twiddles from register-held powers (TwPow), the big twiddles of MODE 1 come
+// from LDS tables, nothing in the loop is conditional (the last round's
+// prefetch goes through an empty descriptor), and the waits the compiler derives are exact: at the loop top
+// vmcnt(#stores) -- loads landed, stores still draining.
+template <int LOGA, int MODE, bool INV, bool TILED>
 __global__ __launch_bounds__(1024, 4) void fourstep_pass_kernel(const float2 *__restrict__ in, float2 *__restrict__ out,
                                                                 const float2 *__restrict__ tw,      // 2^LOGA-point table
-                                                                const float2 *__restrict__ tw_lo,   // exp(-2 pi i m / N), m < 1024
-                                                                const float2 *__restrict__ tw_hi,   // exp(-2 pi i m / (N/1024))
+                                                                const float2 *__restrict__ tw_big,  // three-level table of W_N (above)
                                                                 int log_other,                      // log2 of the other factor
                                                                 uint32_t tiles_per_xform, uint32_t n_items, int paired, float scale)
 {
   using PL = Plan<LOGA, 1024>;
-  constexpr int A = PL::N, C = PL::TPB;
+  constexpr int A = PL::N, C = PL::TPB, NP = PL::NPASS;
   static_assert(A * C == 16 * 1024, "16 points per thread");
+  static_assert(NP >= 2, "at least two passes");
+  constexpr int LAST = NP - 1, HP = NP - 2;
+  constexpr int LRL = PL::lr(LAST), RL = 1 << LRL, NBL = 16 / RL, LNSL = PL::lns(LAST), LNRL = LOGA - LRL;
   extern __shared__ __attribute__((aligned(16))) float2 lds[];
   const uint32_t other = 1u << log_other;  // row length of the matrix the tile is cut from
   const size_t nfull = (size_t)A << log_other;
@@ -58,31 +122,43 @@ __global__ __launch_bounds__(1024, 4) void fourstep_pass_kernel(const float2 *__
   }
   if (first >= n_items) return;
 
-  // MODE 1: the low twiddle table is gathered with a stride of n2 entries per lane: from global
-  // memory that is one 128-byte line per lane per load; from LDS it is an ordinary banked read
-  float2 *lo_lds = lds + PL::LDS_ELEMS;
+  float2 *big = lds + PL::LDS_ELEMS;
   if (MODE == 1) {
-    for (int i = threadIdx.x; i < (1 << kLoLog); i += 1024) lo_lds[i] = tw_lo[i];
+    if (threadIdx.x < kBigEntries) big[threadIdx.x] = tw_big[threadIdx.x];
   }
+  TwPow<PL, 1u << LAST, true> twp;
+  twp.preload(tw, threadIdx.x);
 
+  // element (row a, column c) of leg i: per-lane offset ((t / C) * other + tile * C + t % C) * 8 plus
+  // the scalar i * (1024 / C) * other * 8 (the same form serves the MODE 2 stores)
+  const uint32_t leg_step = (1024u / C) * other * 8u;
+  // MODE 2 reading a blocked intermediate: the tile is one contiguous block, leg i of thread t is
+  // element t + 1024 i of it
+  constexpr bool linear_in = (MODE == 2) && TILED;
+  const uint32_t in_step = linear_in ? 1024u * 8u : leg_step;
   float2 pre[16];
   auto issue = [&](uint32_t item, int t) {
+    // past the last item: a descriptor of zero bytes -- the loads stay in the instruction stream
+    // (no branch, exact waitcnt) but are out of range, return zero and fetch nothing
+    const bool live = item < n_items;
+    if (!live) item = 0;
     const uint32_t tile = item % tiles_per_xform, xf = item / tiles_per_xform;
-    const float2 *__restrict__ src = in + (size_t)xf * nfull + tile * C;
+    const __amdgpu_buffer_rsrc_t rs = xform_rsrc(in + (size_t)xf * nfull, live ? nfull : 0);
+    const uint32_t strided = ((uint32_t)t / C) * other + tile * C + (uint32_t)t % C;
+    const uint32_t voff = (linear_in ? (tile << 14) + (uint32_t)t : strided) * 8u;
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-      const int v = t + i * 1024, c = v % C, a = v / C;
-      pre[i] = src[(size_t)a * other + c];
-    }
+    for (int i = 0; i < 16; i++) pre[i] = buf_load(rs, voff, i * in_step);
   };
   issue(first, threadIdx.x);
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the loop's waits derive from its back edge alone
 
   for (uint32_t item = first; item < n_items; item += stride) {
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));  // keep the per-thread address math inside the loop
+    twp.pin();
     const uint32_t tile = item % tiles_per_xform, xf = item / tiles_per_xform;
     const uint32_t c0 = tile * C;
-    float2 *__restrict__ dst = out + (size_t)xf * nfull;
+    const __amdgpu_buffer_rsrc_t ro = xform_rsrc(out + (size_t)xf * nfull, nfull);
     // ---- stage the prefetched A x C tile: element (row a, column c0 + c) -> sequence c, point a ----
 #pragma unroll
     for (int i = 0; i < 16; i++) {
@@ -92,26 +168,27 @@ __global__ __launch_bounds__(1024, 4) void fourstep_pass_kernel(const float2 *__
       lds[PL::idx(c, a)] = x;
     }
     __syncthreads();
-    if (item + stride < n_items) issue(item + stride, tid);
+    auto hook = [&]() { issue(item + stride, tid); };
 
     auto ld = [&](int t, int e) -> float2 { return lds[PL::idx(t, e)]; };
     if (MODE == 1) {
-      auto st = [&](int t, int k, float2 v) {
-        const uint32_t m = (c0 + (uint32_t)t) * (uint32_t)k;  // < N
-        const float2 w = cmul(lo_lds[m & ((1u << kLoLog) - 1)], tw_hi[m >> kLoLog]);
-        dst[(size_t)(c0 + t) * A + k] = cmul(v, w);
-      };
-      fft_block<PL, true, false>(lds, tw, tid, ld, st);
+      RowStore<LOGA, TILED> st{ro, big, c0, log_other};
+      fft_block_tw<PL, true, false, HP>(lds, twp, tid, ld, st, hook);
     } else {
       auto st = [&](int t, int k, float2 v) { lds[PL::idx(t, k)] = v; };
-      fft_block<PL, true, true>(lds, tw, tid, ld, st);
+      fft_block_tw<PL, true, true, HP>(lds, twp, tid, ld, st, hook);
       __syncthreads();
-#pragma unroll 4
+      // fresh opaque copy: the copy-out's address math must be computed here, not at the loop top
+      // (kept live across the transform it would spill, and a spill reload waits on vmcnt(0))
+      int tid2 = tid;
+      asm volatile("" : "+v"(tid2));
+      const uint32_t voff = (((uint32_t)tid2 / C) * other + c0 + (uint32_t)tid2 % C) * 8u;
+#pragma unroll
       for (int i = 0; i < 16; i++) {
-        const int v = tid + i * 1024, c = v % C, k2 = v / C;
+        const int v = tid2 + i * 1024, c = v % C, k2 = v / C;
         float2 x = lds[PL::idx(c, k2)];
         if (INV) x = make_float2(x.x * scale, -x.y * scale);
-        dst[(size_t)k2 * other + c0 + c] = x;
+        buf_store(ro, voff, i * leg_step, x);
       }
     }
     __syncthreads();  // LDS is free for the next tile
@@ -120,11 +197,17 @@ __global__ __launch_bounds__(1024, 4) void fourstep_pass_kernel(const float2 *__
 
 __global__ void gen_twiddle_lo_kernel(float2 *tw, int logn)
 {
-  uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
-  if (m >= (1u << kLoLog)) return;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (1u << kLoLog)) return;
+  // entry i of the three-level table: exponent i, 128 (i - 128), 16384 (i - 256); rest unused
+  uint64_t m = 0;
+  if (i < kBigB) m = i;
+  else if (i < kBigC) m = (uint64_t)(i - kBigB) << 7;
+  else if (i < kBigEntries) m = (uint64_t)(i - kBigC) << 14;
+  m &= (1ull << logn) - 1;
   double s, c;
   sincospi(2.0 * (double)m / (double)(1ull << logn), &s, &c);
-  tw[m] = make_float2((float)c, (float)(-s));
+  tw[i] = make_float2((float)c, (float)(-s));
 }
 
 hipError_t launch_gen_twiddle_lo(float2 *tw, int logn, hipStream_t stream)
@@ -133,16 +216,16 @@ hipError_t launch_gen_twiddle_lo(float2 *tw, int logn, hipStream_t stream)
   return hipGetLastError();
 }
 
-template <int LOGA, int MODE, bool INV>
-static hipError_t launch_pass(const float2 *in, float2 *out, const float2 *tw, const float2 *tw_lo, const float2 *tw_hi,
-                              int log_other, uint32_t batch, float scale, hipStream_t stream)
+template <int LOGA, int MODE, bool INV, bool TILED>
+static hipError_t launch_pass(const float2 *in, float2 *out, const float2 *tw, const float2 *tw_big, int log_other, uint32_t batch,
+                              float scale, hipStream_t stream)
 {
   using PL = Plan<LOGA, 1024>;
-  const size_t lds_bytes = PL::LDS_BYTES + (MODE == 1 ? sizeof(float2) << kLoLog : 0);
+  const size_t lds_bytes = PL::LDS_BYTES + (MODE == 1 ? sizeof(float2) * kBigEntries : 0);
   static bool attr_done[16] = {false};
   int dev = 0;
   (void)hipGetDevice(&dev);
-  auto kern = fourstep_pass_kernel<LOGA, MODE, INV>;
+  auto kern = fourstep_pass_kernel<LOGA, MODE, INV, TILED>;
   if (dev < 16 && !attr_done[dev]) {
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
@@ -157,17 +240,25 @@ static hipError_t launch_pass(const float2 *in, float2 *out, const float2 *tw, c
   uint32_t grid = n_items < (uint32_t)cus ? n_items : (uint32_t)cus;
   const int paired = (tiles % 2 == 0 && grid >= 16) ? 1 : 0;
   if (paired) grid &= ~15u;
-  kern<<<grid, 1024, lds_bytes, stream>>>(in, out, tw, tw_lo, tw_hi, log_other, tiles, n_items, paired, scale);
+  kern<<<grid, 1024, lds_bytes, stream>>>(in, out, tw, tw_big, log_other, tiles, n_items, paired, scale);
   return hipGetLastError();
 }
 
+// Layout of the intermediate (see RowStore): blocked whenever pass 1's last-pass leg stride Ns is a
+// multiple of pass 2's tile width C2 = 16384 / N2, which holds for N1 >= 512, i.e. N >= 2^17:
+// pass 1 (LOGA = log2 N1) is blocked from LOGA = 9, pass 2 (LOGA = log2 N2) from LOGA = 9 and,
+// for N = 2^17 only, at LOGA = 8.
 template <int MODE, bool INV>
-static hipError_t launch_pass_log(int loga, const float2 *in, float2 *out, const float2 *tw, const float2 *tw_lo,
-                                  const float2 *tw_hi, int log_other, uint32_t batch, float scale, hipStream_t stream)
+static hipError_t launch_pass_log(int loga, const float2 *in, float2 *out, const float2 *tw, const float2 *tw_big, int log_other,
+                                  uint32_t batch, float scale, bool tiled, hipStream_t stream)
 {
   switch (loga) {
-#define C(L) case L: return launch_pass<L, MODE, INV>(in, out, tw, tw_lo, tw_hi, log_other, batch, scale, stream);
-    C(7) C(8) C(9) C(10) C(11)
+#define C(L, T) case L: return launch_pass<L, MODE, INV, T>(in, out, tw, tw_big, log_other, batch, scale, stream);
+    C(7, false)
+    case 8:
+      if (MODE == 2 && tiled) return launch_pass<8, MODE, INV, (MODE == 2)>(in, out, tw, tw_big, log_other, batch, scale, stream);
+      return launch_pass<8, MODE, INV, false>(in, out, tw, tw_big, log_other, batch, scale, stream);
+    C(9, true) C(10, true) C(11, true)
 #undef C
   }
   return hipErrorInvalidValue;
@@ -175,20 +266,21 @@ static hipError_t launch_pass_log(int loga, const float2 *in, float2 *out, const
 
 // data -> work (pass 1) -> data (pass 2).  tw1/tw2: tables of the N1- and N2-point transforms.
 hipError_t launch_cfft_large_f32(int logn, float2 *data, float2 *work, const float2 *tw1, const float2 *tw2,
-                                 const float2 *tw_lo, const float2 *tw_hi, uint32_t batch, bool inverse, hipStream_t stream)
+                                 const float2 *tw_big, uint32_t batch, bool inverse, hipStream_t stream)
 {
   if (batch == 0) return hipSuccess;
   const int log2_ = logn / 2, log1 = logn - log2_;  // N1 >= N2
   const float scale = 1.0f / (float)(1ull << logn);
+  const bool tiled = logn >= 17;
   hipError_t e;
   if (!inverse) {
-    e = launch_pass_log<1, false>(log1, data, work, tw1, tw_lo, tw_hi, log2_, batch, 1.0f, stream);
+    e = launch_pass_log<1, false>(log1, data, work, tw1, tw_big, log2_, batch, 1.0f, tiled, stream);
     if (e != hipSuccess) return e;
-    return launch_pass_log<2, false>(log2_, work, data, tw2, tw_lo, tw_hi, log1, batch, 1.0f, stream);
+    return launch_pass_log<2, false>(log2_, work, data, tw2, tw_big, log1, batch, 1.0f, tiled, stream);
   }
-  e = launch_pass_log<1, true>(log1, data, work, tw1, tw_lo, tw_hi, log2_, batch, 1.0f, stream);
+  e = launch_pass_log<1, true>(log1, data, work, tw1, tw_big, log2_, batch, 1.0f, tiled, stream);
   if (e != hipSuccess) return e;
-  return launch_pass_log<2, true>(log2_, work, data, tw2, tw_lo, tw_hi, log1, batch, scale, stream);
+  return launch_pass_log<2, true>(log2_, work, data, tw2, tw_big, log1, batch, scale, tiled, stream);
 }
 
 }  // namespace armfft

@@ -368,9 +368,17 @@ struct store_is_split : std::false_type {};
 template <class S>
 struct store_is_split<S, std::void_t<decltype(S::SPLIT)>> : std::true_type {};
 
+// ... and one that declares `static constexpr bool SLOT = true` also gets the butterfly and leg it
+// is storing: st(q, r, t, e0, roff, val) -- for per-butterfly state prepared by the caller.
+template <class S, class = void>
+struct store_has_slot : std::false_type {};
+template <class S>
+struct store_has_slot<S, std::void_t<decltype(S::SLOT)>> : std::true_type {};
+
 struct NoHook {
   __device__ __forceinline__ void operator()() const {}
 };
+
 
 template <class PL, int P, bool LDS_IN, bool LDS_OUT, int HP, class TW, class Load, class Store, class Hook>
 __device__ __forceinline__ void fft_pass(float2 *v, float2 *lds, const TW &tw, int tid, Load &ld, Store &st, const float2 *twc, float2 *twn,
@@ -429,7 +437,8 @@ __device__ __forceinline__ void fft_pass(float2 *v, float2 *lds, const TW &tw, i
     if (LAST) {
 #pragma unroll
       for (int r = 0; r < R; r++) {
-        if constexpr (store_is_split<Store>::value) st(t, j0, r << LNS, v[q * R + r]);
+        if constexpr (store_has_slot<Store>::value) st(q, r, t, j0, r << LNS, v[q * R + r]);
+        else if constexpr (store_is_split<Store>::value) st(t, j0, r << LNS, v[q * R + r]);
         else st(t, j0 + (r << LNS), v[q * R + r]);
       }
     } else if (FIRST && R >= 2) {
@@ -476,12 +485,11 @@ struct PassLoop {
 // st() calls of this thread have been issued (no trailing barrier).  LDS_IN / LDS_OUT: set when
 // ld() reads / st() writes the workgroup's LDS (anywhere), so that the core separates them from
 // its own LDS traffic with a barrier.
-template <class PL, bool LDS_IN, bool LDS_OUT, class TW, class Load, class Store>
-__device__ __forceinline__ void fft_block_tw(float2 *lds, const TW &tw, int tid, Load ld, Store st)
+template <class PL, bool LDS_IN, bool LDS_OUT, int HP = -1, class TW, class Load, class Store, class Hook = NoHook>
+__device__ __forceinline__ void fft_block_tw(float2 *lds, const TW &tw, int tid, Load ld, Store st, Hook hook = Hook())
 {
   float2 v[PL::E], twa[PL::E - 1], twb[PL::E - 1];
-  NoHook hook;
-  PassLoop<PL, 0, LDS_IN, LDS_OUT, -1, TW, Load, Store, NoHook>::run(v, lds, tw, tid, ld, st, twa, twb, hook);
+  PassLoop<PL, 0, LDS_IN, LDS_OUT, HP, TW, Load, Store, Hook>::run(v, lds, tw, tid, ld, st, twa, twb, hook);
 }
 
 template <class PL, bool LDS_IN, bool LDS_OUT, class Load, class Store>
