@@ -299,3 +299,59 @@ def test_cfft_fixed_full_batch_checksum():
         torch.cuda.synchronize()
         w = torch.from_numpy(want).cuda()
         assert torch.equal(t.view(batch // sub, sub, 2 * n), w.unsqueeze(0).expand(batch // sub, sub, 2 * n))
+
+
+# ---------------------------------------------------------------- persistent kernels: several rounds per workgroup
+def _chunked(fn, x, chunk=64):
+    """The same transforms, at most `chunk` per launch: every workgroup runs a single round."""
+    return np.concatenate([fn(x[i:i + chunk]) for i in range(0, len(x), chunk)], axis=0)
+
+
+@pytest.mark.parametrize("ifft,bitrev", [(0, 1), (1, 1), (0, 0)])
+@pytest.mark.parametrize("n", [2048, 4096, 8192, 16384])
+def test_cfft_f32_many_rounds_equal_single_round(n, ifft, bitrev):
+    """Sizes whose kernels are persistent (the workgroup loops over transforms, prefetching the
+    next one): a batch of more than two rounds per workgroup plus a ragged tail must give, bit
+    for bit, what one-round launches give (those are the ones checked against the oracle above),
+    and the last transform of the batch is checked against the oracle directly."""
+    G = _gpu()
+    batch = 4133 if n <= 4096 else 1061
+    x = H.rng(1400 + n + ifft).uniform(-1, 1, (batch, 2 * n)).astype(np.float32)
+    got = G.cfft_dev("f32", x, n, ifft, bitrev=bitrev)
+    ref = _chunked(lambda c: G.cfft_dev("f32", c, n, ifft, bitrev=bitrev), x)
+    assert np.array_equal(got, ref)
+    for b in (0, batch // 2, batch - 1):
+        want = x[b].copy()
+        assert H.oracle().orc_cfft_radix2_f32(ptr(want, c_f), n, ifft, 1) == 0
+        if bitrev:
+            assert H.rel_l2(got[b], want) <= 5e-7
+
+
+@pytest.mark.parametrize("ifft", [0, 1])
+@pytest.mark.parametrize("n", [2048, 4096, 8192, 16384])
+def test_rfft_f32_many_rounds_equal_single_round(n, ifft):
+    G = _gpu()
+    batch = 4133 if n <= 4096 else 1061
+    x = H.rng(1500 + n + ifft).uniform(-1, 1, (batch, n)).astype(np.float32)
+    if ifft:
+        x = G.rfft_dev(x, n, 0)[0]          # a valid packed spectrum
+    got, src_after = G.rfft_dev(x, n, ifft)
+    ref = _chunked(lambda c: G.rfft_dev(c, n, ifft)[0], x)
+    assert np.array_equal(got, ref)
+    assert np.array_equal(src_after, x)
+    if n <= 4096:                           # the reference's own size range: last transform vs oracle
+        want, tmp = np.zeros((1, n), np.float32), x[-1:].copy()
+        assert H.oracle().orc_rfft_fast_f32_batch(ptr(tmp, c_f), ptr(want, c_f), n, 1, ifft) == 0
+        assert H.rel_l2(got[-1], want[0]) <= 5e-7
+
+
+@pytest.mark.parametrize("ifft", [0, 1])
+def test_cfft_q15_4096_many_rounds_bit_exact(ifft):
+    """The persistent q15 kernel (5 workgroups per CU): three rounds and a tail, against the oracle."""
+    G = _gpu()
+    n, batch = 4096, 2 * 1280 + 37
+    x = H.rng(1600 + ifft).integers(-16384, 16384, (batch, 2 * n)).astype(np.int16)
+    want = x.copy()
+    assert H.oracle().orc_cfft_q15_batch(ptr(want, c_i16), n, batch, ifft, 1, 0) == 0
+    got = G.cfft_dev("q15", x, n, ifft)
+    assert np.array_equal(got, want)
