@@ -391,14 +391,16 @@ __global__ __launch_bounds__(GPlan<LOGN>::T, GPlan<LOGN>::T >= 1024 ? 4 : 3) voi
 
   fold_and_fft<PL>(lds, wblk, tw, sig, ors, packed, fd, FS, 0, n_ms, spm, tid);
   // conj(Z) in the order the first pass consumes its inputs
+  // ... scaled by 1/N here, once per Doppler bin instead of once per output of every PRN: a power
+  // of two, so every later product and sum is the unscaled one times 2^-LOGN exactly
+  const float inv_n = 1.0f / (float)N;
   float2 zc[16];
   for_each_first_pass_input<PL>(tid, [&](int slot, int, int e) {
     const float2 z = lds[PL::idx(0, e)];
-    zc[slot] = make_float2(z.x, -z.y);
+    zc[slot] = make_float2(z.x * inv_n, -z.y * inv_n);
   });
   __syncthreads();
 
-  const float inv_n = 1.0f / (float)N;
   // twiddles of the per-PRN transforms: powers of thread-constant bases held in registers for the
   // whole PRN loop (TwPow), no twiddle loads or address math per transform
   // (up to 4096 points; the larger sizes are register-bound and keep the table)
@@ -418,10 +420,7 @@ __global__ __launch_bounds__(GPlan<LOGN>::T, GPlan<LOGN>::T >= 1024 ? 4 : 3) voi
       const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(cs, j * 8, roff * 8, 0);
       v[slot] = cmul(zc[slot], make_float2(__uint_as_float(w[0]), __uint_as_float(w[1])));
     });
-    auto st = [&](int, int k, float2 y) {
-      const float re = y.x * inv_n, im = y.y * inv_n;
-      magl[mag_idx(k)] = sqrtf(re * re + im * im);
-    };
+    auto st = [&](int, int k, float2 y) { magl[mag_idx(k)] = sqrtf(y.x * y.x + y.y * y.y); };
     fft_block_preloaded<PL, true>(v, lds, twp, lt, st);
     __syncthreads();
     auto mag = [&](int m) -> float { return magl[mag_idx(m)]; };
