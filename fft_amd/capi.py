@@ -2,11 +2,11 @@
 Include/dsp/transform_functions.h:284-298, :352-366, :416-430, :827-832)."""
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int16, c_int32, c_uint8, c_uint16, c_uint32, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int16, c_int32, c_uint8, c_uint16, c_uint32, c_uint64, c_void_p
 
 __all__ = [
     "lib", "lib_path", "ARM_MATH_SUCCESS", "ARM_MATH_ARGUMENT_ERROR",
-    "arm_rfft_instance_q15", "arm_rfft_instance_q31", "gnss_acq_result", "gnss_top2", "arm_cfft_radix2_instance_f32", "arm_cfft_instance_u32_f32", "arm_cfft_instance_f32", "arm_cfft_instance_q15", "arm_cfft_instance_q31", "arm_rfft_fast_instance_f32",
+    "arm_rfft_instance_q15", "arm_rfft_instance_q31", "gnss_acq_result", "gnss_top2", "bb_meas_t", "bb_meas_sat_t", "SYS_GPS", "SYS_GAL", "arm_cfft_radix2_instance_f32", "arm_cfft_instance_u32_f32", "arm_cfft_instance_f32", "arm_cfft_instance_q15", "arm_cfft_instance_q31", "arm_rfft_fast_instance_f32",
     "last_error", "EXPORTED_SYMBOLS",
 ]
 
@@ -61,6 +61,18 @@ class gnss_acq_result(Structure):
                 ("doppler_bin", c_int32), ("prn", c_int32), ("snr_db", c_float), ("code_phase_interp", c_float)]
 
 
+class bb_meas_sat_t(Structure):      # Include/msb_funcs.h:24-33
+    _fields_ = [("time_tag", c_double), ("pseudorange", c_float), ("code_phase", c_float), ("doppler", c_float),
+                ("carr_phase", c_float), ("cno", c_float), ("prn", c_uint16), ("constellation", c_uint16)]
+
+
+class bb_meas_t(Structure):          # Include/msb_funcs.h:35-40
+    _fields_ = [("time", c_uint64), ("sec", c_double), ("num_sat", c_int), ("sats", bb_meas_sat_t * 20)]
+
+
+SYS_GPS, SYS_GAL = 1, 2
+
+
 class gnss_top2(Structure):
     _fields_ = [("val1", c_float), ("idx1", c_int32), ("val2", c_float), ("idx2", c_int32)]
 
@@ -92,6 +104,7 @@ EXPORTED_SYMBOLS = (
        "arm_rfft_q15_dev", "arm_rfft_q31_dev"]
     + ["arm_rfft_init_%d_%s" % (n, q) for n in (32, 64, 128, 256, 512, 1024, 2048, 4096, 8192) for q in ("q15", "q31")]
     + ["up_sample_N_to_M", "up_sample_10k_to_16k", "iq_resamp_zero_phase_dev", "iq_resamp_zero_phase_count"]
+    + ["write_bb_msb", "read_bb_msb", "gnss_acq_to_meas"]
     + ["arm_fft_mi355_set_device", "arm_fft_mi355_warm", "arm_fft_mi355_last_error",
        "arm_fft_mi355_set_twiddle_rounding", "arm_fft_mi355_version"]
 )
@@ -180,6 +193,10 @@ def _load():
     L.iq_resamp_zero_phase_dev.argtypes = [dbl, dbl, i32, dbl, c_void_p, u32, c_void_p, u32, u32, POINTER(c_uint32), c_void_p]
     L.iq_resamp_zero_phase_dev.restype = c_int
     L.iq_resamp_zero_phase_count.argtypes, L.iq_resamp_zero_phase_count.restype = [dbl, dbl, i32, dbl, u32, u32], c_uint32
+    L.write_bb_msb.argtypes, L.write_bb_msb.restype = [POINTER(bb_meas_t), c_void_p, c_int], c_int
+    L.read_bb_msb.argtypes, L.read_bb_msb.restype = [c_void_p, c_int, POINTER(bb_meas_t)], None
+    L.gnss_acq_to_meas.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_float, c_float, c_uint16, POINTER(bb_meas_t)]
+    L.gnss_acq_to_meas.restype = c_int
     L.arm_fft_mi355_set_device.argtypes, L.arm_fft_mi355_set_device.restype = [c_int], c_int
     L.arm_fft_mi355_warm.argtypes, L.arm_fft_mi355_warm.restype = [c_int, u32], c_int
     L.arm_fft_mi355_last_error.argtypes, L.arm_fft_mi355_last_error.restype = [], c_char_p

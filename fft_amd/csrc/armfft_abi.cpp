@@ -962,3 +962,125 @@ void arm_rfft_fast_f32(const arm_rfft_fast_instance_f32 *S, float32_t *p, float3
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------
+// msb measurement wire format (msb_funcs.c:47-233): host-side bit packing, no GPU
+// ------------------------------------------------------------------------------------------
+namespace {
+struct BitOut {
+  uint8_t *buf;
+  int cap_bits, pos;
+  bool ok;
+  // MSB-first, the low num_bits of val (msb_funcs.c:47-77)
+  void put(uint64_t val, int num_bits)
+  {
+    for (int i = num_bits - 1; i >= 0; --i) {
+      if (pos >= cap_bits) { ok = false; return; }
+      const uint8_t mask = (uint8_t)(1u << (7 - (pos & 7)));
+      if ((val >> i) & 1u) buf[pos >> 3] |= mask; else buf[pos >> 3] &= (uint8_t)~mask;
+      ++pos;
+    }
+  }
+};
+struct BitIn {
+  const uint8_t *buf;
+  int size_bits, pos;
+  // msb_funcs.c:14-43: a bit past the end reads as -1, which ORs all ones from that position up
+  int64_t get(unsigned num_bit, bool is_signed)
+  {
+    uint64_t ans = 0;
+    for (unsigned i = 0; i < num_bit; i++) {
+      int64_t bit;
+      if (pos >= size_bits) bit = -1;
+      else { bit = (buf[pos >> 3] >> (7 - (pos & 7))) & 1; pos++; }
+      ans |= (uint64_t)bit << (num_bit - (i + 1));
+    }
+    if (is_signed && ((ans >> (num_bit - 1)) & 1u)) ans |= ~(uint64_t)0 << num_bit;
+    return (int64_t)ans;
+  }
+};
+// per-satellite fields (msb_funcs.c:108-113, :135-140): float division, truncation toward zero
+void put_sat(BitOut &o, const bb_meas_sat_t &s, int phase_bits)
+{
+  o.put((uint64_t)(int64_t)(s.code_phase / 9.54e-7f), phase_bits);
+  o.put((uint64_t)(int64_t)(s.doppler / 2.0f), 13);
+  o.put((uint64_t)(int64_t)((s.cno - 28) / 4), 4);
+}
+}  // namespace
+
+extern "C" int write_bb_msb(const bb_meas_t *m, uint8_t *bin_buff, int buff_size)
+{
+  if (!m || !bin_buff || buff_size <= 0 || m->num_sat < 0 || m->num_sat > 20) { set_error("write_bb_msb: bad argument"); return -1; }
+  memset(bin_buff, 0, (size_t)buff_size);
+  BitOut o{bin_buff, buff_size * 8, 0, true};
+  uint64_t mask = 0;
+  for (int i = 0; i < m->num_sat; i++)
+    if (m->sats[i].constellation == SYS_GPS) mask |= (uint64_t)1 << ((m->sats[i].prn - 1) & 63);
+  o.put(mask, 32);
+  for (int i = 0; i < m->num_sat; i++)
+    if (m->sats[i].constellation == SYS_GPS) put_sat(o, m->sats[i], 20);
+  int gal = 0;
+  for (int i = 0; i < m->num_sat; i++)
+    if (m->sats[i].constellation == SYS_GAL) { gal = 1; break; }
+  o.put((uint64_t)gal, 3);
+  if (gal) {
+    mask = 0;
+    for (int i = 0; i < m->num_sat; i++)
+      if (m->sats[i].constellation == SYS_GAL) mask |= (uint64_t)1 << ((m->sats[i].prn - 1) & 63);
+    o.put(mask, 50);
+    for (int i = 0; i < m->num_sat; i++)
+      if (m->sats[i].constellation == SYS_GAL) put_sat(o, m->sats[i], 22);
+  }
+  if (!o.ok) { set_error("write_bb_msb: buffer of %d bytes is too small", buff_size); return -1; }
+  return o.pos / 8;
+}
+
+extern "C" void read_bb_msb(uint8_t *bin_buff, int bin_size, bb_meas_t *m)
+{
+  if (!bin_buff || !m || bin_size < 0) { set_error("read_bb_msb: bad argument"); return; }
+  BitIn in{bin_buff, bin_size * 8, 0};
+  auto section = [&](int first, unsigned mask_bits, unsigned phase_bits, uint16_t constellation) {
+    const uint64_t mask = (uint64_t)in.get(mask_bits, false);
+    int prns[64], n = 0;
+    for (unsigned i = 0; i < mask_bits; i++)
+      if ((mask >> i) & 1u) prns[n++] = (int)i + 1;
+    for (int i = 0; i < n; i++) {
+      const int64_t code_phase = in.get(phase_bits, false), doppler = in.get(13, true), cno = in.get(4, false);
+      if (first + i >= 20) continue;  // the reference would overrun sats[]
+      bb_meas_sat_t &s = m->sats[first + i];
+      s.time_tag = (double)m->time + m->sec;
+      s.pseudorange = 0;
+      s.code_phase = ((float)code_phase) * 9.54e-7f;
+      s.cno = (float)(cno * 4 + 28);
+      s.doppler = (float)(2 * doppler);
+      s.prn = (uint16_t)prns[i];
+      s.constellation = constellation;
+    }
+    return n;
+  };
+  m->num_sat = section(0, 32, 20, SYS_GPS);
+  if (in.get(3, false) == 1) m->num_sat += section(m->num_sat, 50, 22, SYS_GAL);
+}
+
+extern "C" int gnss_acq_to_meas(const gnss_acq_result *best, int n, const float32_t *dopplers_hz, int n_dop, int fft_len, float ratio_min,
+                                float cno_offset_db, uint16_t constellation, bb_meas_t *meas)
+{
+  if (!best || n < 0 || !dopplers_hz || n_dop <= 0 || fft_len <= 0 || !meas || meas->num_sat < 0 || meas->num_sat > 20) {
+    set_error("gnss_acq_to_meas: bad argument");
+    return -1;
+  }
+  int added = 0;
+  for (int i = 0; i < n && meas->num_sat < 20; i++) {
+    const gnss_acq_result &r = best[i];
+    if (!(r.peak / r.second > ratio_min)) continue;                       // CMSIS.cpp:737
+    if (r.doppler_bin < 0 || r.doppler_bin >= n_dop) { set_error("gnss_acq_to_meas: row %d has Doppler bin %d", i, r.doppler_bin); return -1; }
+    bb_meas_sat_t &s = meas->sats[meas->num_sat++];
+    s.prn = (uint16_t)r.prn;
+    s.code_phase = r.code_phase_interp / (float)fft_len;                  // CMSIS.cpp:739
+    s.doppler = dopplers_hz[r.doppler_bin];
+    s.cno = r.snr_db + cno_offset_db;                                      // CMSIS.cpp:729, :741
+    s.constellation = constellation;
+    added++;
+  }
+  return added;
+}

@@ -361,6 +361,51 @@ arm_status iq_resamp_zero_phase_dev(double fin_hz, double fout_hz, int32_t ntaps
                                     float32_t *out_dev, uint32_t n_out_cap, uint32_t batch, uint32_t *n_out, void *stream);
 uint32_t iq_resamp_zero_phase_count(double fin_hz, double fout_hz, int32_t ntaps, double cutoff, uint32_t n_in, uint32_t n_out_cap);
 
+/* ---- measurement wire format "msb" (Include/msb_funcs.h, Source/TransformFunctions/msb_funcs.c) ----
+ * The fork's downstream tools read acquisition results as a bit-packed record: a 32-bit GPS PRN
+ * mask, then per GPS satellite (in the order of sats[]) code phase (20 bits, units of 9.54e-7 ms),
+ * Doppler (13 bits signed, 2 Hz) and C/N0 (4 bits, (cno - 28) / 4); 3 bits "Galileo present", and
+ * if so a 50-bit PRN mask and 22 + 13 + 4 bits per Galileo satellite (msb_funcs.c:92-145).
+ * Host-side byte work on at most 20 satellites: plain C on the CPU, no GPU involved.  Structures
+ * are the reference's (msb_funcs.h:16-41). */
+#define SYS_GPS 0x01
+#define SYS_GAL 0x02
+typedef struct {
+  double time_tag;
+  float pseudorange;
+  float code_phase;   /* ms */
+  float doppler;      /* Hz */
+  float carr_phase;
+  float cno;          /* dB-Hz */
+  uint16_t prn;
+  uint16_t constellation;
+} bb_meas_sat_t;
+typedef struct {
+  uint64_t time;
+  double sec;
+  int num_sat;
+  bb_meas_sat_t sats[20];
+} bb_meas_t;
+/* msb_funcs.c:92-145: clears bin_buff[0 .. buff_size), packs, returns the number of WHOLE bytes
+ * used (bit_pos / 8: trailing bits of a partial last byte are in the buffer but not counted, as
+ * in the reference).  Extension: returns -1 instead of overrunning when buff_size is too small
+ * or an argument is NULL / num_sat is outside 0..20 (the reference does not check). */
+int write_bb_msb(const bb_meas_t *measurements, uint8_t *bin_buff, int buff_size);
+/* msb_funcs.c:152-233 without its printf chatter: fills num_sat and sats[] (time_tag from the
+ * caller-set time + sec, pseudorange 0, carr_phase untouched); bits past bin_size read as the
+ * reference's error value (-1, i.e. all ones from that bit up).  More than 20 satellites in the
+ * record are counted in num_sat but not stored (the reference would overrun sats[]). */
+void read_bb_msb(uint8_t *bin_buff, int bin_size, bb_meas_t *measurements);
+/* The acceptance step between acquisition and the record (CMSIS/CMSIS.cpp:737-748, :954-966):
+ * every row of best[0 .. n) whose peak / second exceeds ratio_min is appended to meas->sats[]
+ * (up to 20) with code_phase = code_phase_interp / fft_len [ms], doppler = dopplers_hz[bin]
+ * (the signal's Doppler: the reference searches with the negated replica Doppler and reports the
+ * negation, i.e. the same quantity),
+ * cno = snr_db + cno_offset_db (35 in the GPS L1 flow, 0 in the L5 flow).  Returns the number
+ * appended, -1 on a bad argument. */
+int gnss_acq_to_meas(const gnss_acq_result *best, int n, const float32_t *dopplers_hz, int n_dop, int fft_len, float ratio_min,
+                     float cno_offset_db, uint16_t constellation, bb_meas_t *meas);
+
 /* ---- library services (no counterpart in the reference) ---- */
 /* Select the GPU used by the calling thread's host-pointer entry points and build nothing else;
  * optional (device 0 / the current HIP device is used otherwise). */

@@ -44,7 +44,7 @@ def oracle():
     global _oracle
     if _oracle is None:
         so = os.path.join(ORACLE_DIR, "liboracle.so")
-        srcs = [os.path.join(ORACLE_DIR, f) for f in ("armfft_oracle.c", "gnss_oracle.c", "rfft_fixed_oracle.c", "armfft_oracle.h")]
+        srcs = [os.path.join(ORACLE_DIR, f) for f in ("armfft_oracle.c", "gnss_oracle.c", "rfft_fixed_oracle.c", "msb_oracle.c", "armfft_oracle.h")]
         if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
             subprocess.run(["make", "-C", ORACLE_DIR, "liboracle.so"], check=True, capture_output=True)
         L = ctypes.CDLL(so)
