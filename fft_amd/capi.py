@@ -104,7 +104,7 @@ EXPORTED_SYMBOLS = (
        "arm_rfft_q15_dev", "arm_rfft_q31_dev"]
     + ["arm_rfft_init_%d_%s" % (n, q) for n in (32, 64, 128, 256, 512, 1024, 2048, 4096, 8192) for q in ("q15", "q31")]
     + ["up_sample_N_to_M", "up_sample_10k_to_16k", "iq_resamp_zero_phase_dev", "iq_resamp_zero_phase_count"]
-    + ["write_bb_msb", "read_bb_msb", "gnss_acq_to_meas"]
+    + ["write_bb_msb", "read_bb_msb", "gnss_acq_to_meas", "gnss_acq_plan_create_replicas", "gnss_l5_generate_I_dev"]
     + ["arm_fft_mi355_set_device", "arm_fft_mi355_warm", "arm_fft_mi355_last_error",
        "arm_fft_mi355_set_twiddle_rounding", "arm_fft_mi355_version"]
 )
@@ -197,6 +197,9 @@ def _load():
     L.read_bb_msb.argtypes, L.read_bb_msb.restype = [c_void_p, c_int, POINTER(bb_meas_t)], None
     L.gnss_acq_to_meas.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_float, c_float, c_uint16, POINTER(bb_meas_t)]
     L.gnss_acq_to_meas.restype = c_int
+    L.gnss_acq_plan_create_replicas.argtypes = [POINTER(c_void_p), u32, u32, u32, c_void_p, c_void_p, u32, c_void_p, u32]
+    L.gnss_acq_plan_create_replicas.restype = c_int
+    L.gnss_l5_generate_I_dev.argtypes, L.gnss_l5_generate_I_dev.restype = [i32, u32, c_void_p], c_int
     L.arm_fft_mi355_set_device.argtypes, L.arm_fft_mi355_set_device.restype = [c_int], c_int
     L.arm_fft_mi355_warm.argtypes, L.arm_fft_mi355_warm.restype = [c_int, u32], c_int
     L.arm_fft_mi355_last_error.argtypes, L.arm_fft_mi355_last_error.restype = [], c_char_p

@@ -71,6 +71,51 @@ __global__ void gnss_code_kernel(const int32_t *__restrict__ prns, int8_t *__res
   }
 }
 
+// l5_generate_I from the epoch (gnss_codes.c:153-204): two 13-stage registers, all ones (:147-151),
+// right shift with the feedback injected at stage 13 (:101-106; G1 taps 13,12,10,9,1 :90-94, G2
+// taps 13,12,8,7,6,4,3,1 :95-99), chip = G1 stage 13 ^ two PRN-specific G2 stages (L5I_TAPS
+// :115-124), 0 -> +1, 1 -> -1; the registers run on across the 10230-chip boundary (:194-197 wraps
+// only the counter).  A tap number 0 reads as 0 (the reference shifts by 2^32 - 1 there, which the
+// hosts it runs on take modulo 32).  Same structure as gnss_code_kernel: one thread clocks, all combine.
+__constant__ uint8_t k_l5i_taps[38][2] = {
+    {0, 0},
+    {1, 5}, {2, 6}, {3, 7}, {4, 8}, {0, 8}, {1, 9}, {0, 7}, {1, 8}, {2, 9}, {1, 2},
+    {2, 3}, {4, 5}, {5, 6}, {6, 7}, {7, 8}, {8, 9}, {0, 3}, {1, 4}, {2, 5}, {3, 6},
+    {4, 7}, {5, 8}, {0, 2}, {3, 5}, {4, 6}, {5, 7}, {6, 8}, {7, 9}, {0, 5}, {1, 6},
+    {2, 7}, {3, 8}, {4, 9}, {3, 9}, {0, 6}, {1, 7}, {3, 9},
+};
+constexpr int kL5Chunk = 2048;  // chips per round of the generator (LDS staging)
+__global__ void gnss_l5_code_kernel(int prn, uint32_t n_chips, int8_t *__restrict__ out)
+{
+  __shared__ uint16_t g2_state[kL5Chunk];
+  __shared__ uint8_t g1_out[kL5Chunk];
+  __shared__ uint32_t carry[2];
+  if (threadIdx.x == 0) { carry[0] = 0x1FFFu; carry[1] = 0x1FFFu; }
+  const unsigned t1 = k_l5i_taps[prn][0], t2 = k_l5i_taps[prn][1];
+  for (uint32_t base = 0; base < n_chips; base += kL5Chunk) {
+    const uint32_t cnt = n_chips - base < (uint32_t)kL5Chunk ? n_chips - base : (uint32_t)kL5Chunk;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t g1 = carry[0], g2 = carry[1];
+      for (uint32_t i = 0; i < cnt; i++) {
+        g1_out[i] = (g1 >> 12) & 1u;
+        g2_state[i] = (uint16_t)g2;
+        const uint32_t f1 = ((g1 >> 12) ^ (g1 >> 11) ^ (g1 >> 9) ^ (g1 >> 8) ^ g1) & 1u;
+        const uint32_t f2 = ((g2 >> 12) ^ (g2 >> 11) ^ (g2 >> 7) ^ (g2 >> 6) ^ (g2 >> 5) ^ (g2 >> 3) ^ (g2 >> 2) ^ g2) & 1u;
+        g1 = ((g1 >> 1) | (f1 << 12)) & 0x1FFFu;
+        g2 = ((g2 >> 1) | (f2 << 12)) & 0x1FFFu;
+      }
+      carry[0] = g1;
+      carry[1] = g2;
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) {
+      const unsigned a = t1 ? (g2_state[i] >> (t1 - 1u)) & 1u : 0u, b = t2 ? (g2_state[i] >> (t2 - 1u)) & 1u : 0u;
+      out[base + i] = (g1_out[i] ^ a ^ b) ? -1 : 1;
+    }
+  }
+}
+
 // probe of getCode: out[n] = chip[(n / spc) mod 1023], n < num * spc
 __global__ void gnss_expand_code_kernel(const int8_t *__restrict__ chips, int32_t *__restrict__ out, int total, int spc)
 {
@@ -369,7 +414,7 @@ __global__ __launch_bounds__(GPlan<LOGN>::T, GPlan<LOGN>::T >= 1024 ? 4 : 3) voi
     int packed,
     const float2 *__restrict__ spectra,  // [n_prn][N]
     const float2 *__restrict__ tw, const float *__restrict__ dopplers, const int32_t *__restrict__ prns, int n_prn, int n_dop,
-    int dop_begin, int n_ms, int spm, int spc, int sep,
+    int dop_begin, int n_ms, int spm, double fs_hz, int sep,
     gnss_acq_result *__restrict__ all)   // [n_scenes][n_prn][n_dop]
 {
   using PL = GPlan<LOGN>;
@@ -384,7 +429,7 @@ __global__ __launch_bounds__(GPlan<LOGN>::T, GPlan<LOGN>::T >= 1024 ? 4 : 3) voi
 
   const int tid = threadIdx.x;
   const int d = dop_begin + blockIdx.x, scene = blockIdx.y;
-  const double FS = 1.023e6 * (double)spc;
+  const double FS = fs_hz;
   const double fd = (double)dopplers[d];
   const float2 *__restrict__ sig = reinterpret_cast<const float2 *>(signal_any) + (size_t)scene * n_ms * spm;
   const uint8_t *__restrict__ ors = reinterpret_cast<const uint8_t *>(signal_any) + (size_t)scene * ors_bytes(n_ms * spm);
@@ -443,7 +488,7 @@ __global__ __launch_bounds__(GPlan<LOGN>::T, GPlan<LOGN>::T >= 1024 ? 4 : 3) voi
 template <int LOGN>
 __global__ __launch_bounds__(GPlan<LOGN>::T, 4) void gnss_group_spectra_kernel(const void *__restrict__ signal_any, int packed,
                                                                               const float2 *__restrict__ tw, const float *__restrict__ dopplers,
-                                                                              int dop_begin, int n_ms, int ms_per_group, int spm, int spc,
+                                                                              int dop_begin, int n_ms, int ms_per_group, int spm, double fs_hz,
                                                                               float2 *__restrict__ work)  // [scene][d_local][group][N]
 {
   using PL = GPlan<LOGN>;
@@ -451,7 +496,7 @@ __global__ __launch_bounds__(GPlan<LOGN>::T, 4) void gnss_group_spectra_kernel(c
   extern __shared__ __attribute__((aligned(16))) float2 lds[];
   float2 *wblk = lds + PL::LDS_ELEMS;
   const int tid = threadIdx.x, g = blockIdx.z, scene = blockIdx.y, n_groups = gridDim.z;
-  const double FS = 1.023e6 * (double)spc, fd = (double)dopplers[dop_begin + blockIdx.x];
+  const double FS = fs_hz, fd = (double)dopplers[dop_begin + blockIdx.x];
   const float2 *__restrict__ sig = reinterpret_cast<const float2 *>(signal_any) + (size_t)scene * n_ms * spm;
   const uint8_t *__restrict__ ors = reinterpret_cast<const uint8_t *>(signal_any) + (size_t)scene * ors_bytes(n_ms * spm);
   fold_and_fft<PL>(lds, wblk, tw, sig, ors, packed, fd, FS, g * ms_per_group, ms_per_group, spm, tid);
@@ -543,6 +588,7 @@ using namespace armfft;
 struct gnss_acq_plan {
   int device = 0;
   int logn = 0, fft_len = 0, spm = 0, n_ms = 0, spc = 0, n_prn = 0, n_dop = 0, pk_sep = 3;
+  double fs_hz = 0.0;  // sample rate of the wipe-off: 1.023e6 * spc (C/A plans), 1000 * spm (replica plans)
   int32_t *prns_dev = nullptr;
   float *dops_dev = nullptr;
   int8_t *chips_dev = nullptr;
@@ -578,7 +624,7 @@ hipError_t launch_acquire(const gnss_acq_plan *pl, const void *sig, int packed, 
   hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   k<<<dim3(d1 - d0, n_scenes), PL::T, lds, s>>>(sig, packed, pl->spectra_dev, pl->tw, pl->dops_dev, pl->prns_dev, pl->n_prn, pl->n_dop, d0,
-                                                pl->n_ms, pl->spm, pl->spc, pl->pk_sep, all);
+                                                pl->n_ms, pl->spm, pl->fs_hz, pl->pk_sep, all);
   return hipGetLastError();
 }
 
@@ -593,7 +639,7 @@ hipError_t launch_groups(const gnss_acq_plan *pl, const void *sig, int packed, u
   hipError_t e = hipFuncSetAttribute((const void *)ka, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a);
   if (e != hipSuccess) return e;
   ka<<<dim3(d1 - d0, n_scenes, n_groups), PL::T, lds_a, s>>>(sig, packed, pl->tw, pl->dops_dev, d0, pl->n_ms, pl->n_ms / n_groups, pl->spm,
-                                                             pl->spc, work);
+                                                             pl->fs_hz, work);
   if ((e = hipGetLastError()) != hipSuccess) return e;
   if (mode == 1) {
     auto kb = gnss_accumulate_kernel<LOGN, 1>;
@@ -668,6 +714,7 @@ arm_status gnss_acq_plan_create(gnss_acq_plan **out, uint32_t fft_len, uint32_t 
   gnss_acq_plan *pl = new gnss_acq_plan;
   if (!hip_ok(hipGetDevice(&pl->device), "hipGetDevice")) { delete pl; return ARM_MATH_ARGUMENT_ERROR; }
   pl->logn = logn; pl->fft_len = (int)fft_len; pl->spm = (int)samples_per_ms; pl->n_ms = (int)n_ms; pl->spc = (int)samples_per_chip;
+  pl->fs_hz = 1.023e6 * (double)samples_per_chip;
   pl->n_prn = (int)n_prn; pl->n_dop = (int)n_dop;
   pl->tw = dev_twiddle_f32(logn);
   bool ok = pl->tw != nullptr;
@@ -814,6 +861,54 @@ static arm_status chips_for(int prn, int8_t **chips)
   }
   (void)hipFree(p);
   if (!ok) { (void)hipFree(*chips); *chips = nullptr; return ARM_MATH_ARGUMENT_ERROR; }
+  return ARM_MATH_SUCCESS;
+}
+
+arm_status gnss_l5_generate_I_dev(int32_t prn, uint32_t n_chips, int8_t *out_dev)
+{
+  if (!out_dev) { set_error("gnss_l5_generate_I_dev: null output"); return ARM_MATH_ARGUMENT_ERROR; }
+  if (prn <= 0 || prn > 37) { set_error("gnss_l5_generate_I_dev: PRN %d outside 1..37", prn); return ARM_MATH_ARGUMENT_ERROR; }  // :155
+  if (n_chips == 0) return ARM_MATH_SUCCESS;
+  gnss_l5_code_kernel<<<1, 256, 0, nullptr>>>(prn, n_chips, out_dev);
+  return hip_ok(hipGetLastError(), "gnss_l5_code_kernel") && hip_ok(hipStreamSynchronize(nullptr), "synchronise") ? ARM_MATH_SUCCESS
+                                                                                                                 : ARM_MATH_ARGUMENT_ERROR;
+}
+
+arm_status gnss_acq_plan_create_replicas(gnss_acq_plan **out, uint32_t fft_len, uint32_t samples_per_ms, uint32_t n_ms,
+                                         const float *replicas_dev, const int32_t *prn_labels, uint32_t n_prn, const float *dopplers_hz,
+                                         uint32_t n_dop)
+{
+  if (!out || !replicas_dev || !prn_labels || !dopplers_hz) { set_error("gnss_acq_plan_create_replicas: null argument"); return ARM_MATH_ARGUMENT_ERROR; }
+  *out = nullptr;
+  int logn = -1;
+  for (int l = 10; l <= 14; l++)
+    if (fft_len == (1u << l)) logn = l;
+  if (logn < 0) { set_error("gnss_acq_plan_create_replicas: fft_len %u is not a power of two in 1024..16384", fft_len); return ARM_MATH_ARGUMENT_ERROR; }
+  if (samples_per_ms == 0 || samples_per_ms > fft_len || n_ms == 0 || n_ms > (uint32_t)kMaxMs || n_prn == 0 || n_prn > 64 || n_dop == 0 ||
+      n_dop > 32768) {
+    set_error("gnss_acq_plan_create_replicas: bad geometry (samples_per_ms %u <= fft_len, n_ms 1..%d, n_prn 1..64, n_dop 1..32768)",
+              samples_per_ms, kMaxMs);
+    return ARM_MATH_ARGUMENT_ERROR;
+  }
+  gnss_acq_plan *pl = new gnss_acq_plan;
+  if (!hip_ok(hipGetDevice(&pl->device), "hipGetDevice")) { delete pl; return ARM_MATH_ARGUMENT_ERROR; }
+  pl->logn = logn; pl->fft_len = (int)fft_len; pl->spm = (int)samples_per_ms; pl->n_ms = (int)n_ms; pl->spc = 0;
+  pl->fs_hz = 1000.0 * (double)samples_per_ms;   // one millisecond = samples_per_ms samples
+  pl->n_prn = (int)n_prn; pl->n_dop = (int)n_dop;
+  pl->tw = dev_twiddle_f32(logn);
+  const size_t spec_bytes = sizeof(float2) * (size_t)n_prn * fft_len;
+  bool ok = pl->tw != nullptr;
+  ok = ok && hip_ok(hipMalloc((void **)&pl->prns_dev, sizeof(int32_t) * n_prn), "hipMalloc(prns)");
+  ok = ok && hip_ok(hipMalloc((void **)&pl->dops_dev, sizeof(float) * n_dop), "hipMalloc(dopplers)");
+  ok = ok && hip_ok(hipMalloc((void **)&pl->spectra_dev, spec_bytes), "hipMalloc(code spectra)");
+  ok = ok && hip_ok(hipMemcpy(pl->prns_dev, prn_labels, sizeof(int32_t) * n_prn, hipMemcpyHostToDevice), "hipMemcpy(prns)");
+  ok = ok && hip_ok(hipMemcpy(pl->dops_dev, dopplers_hz, sizeof(float) * n_dop, hipMemcpyHostToDevice), "hipMemcpy(dopplers)");
+  // spectra = FFT(replica), the same forward transform the acquisition kernel runs
+  ok = ok && hip_ok(hipMemcpyAsync(pl->spectra_dev, replicas_dev, spec_bytes, hipMemcpyDeviceToDevice, nullptr), "hipMemcpy(replicas)");
+  ok = ok && hip_ok(launch_cfft_f32(logn, pl->spectra_dev, pl->tw, n_prn, false, 0, nullptr), "replica spectra") &&
+       hip_ok(hipStreamSynchronize(nullptr), "plan synchronise");
+  if (!ok) { gnss_acq_plan_destroy(pl); return ARM_MATH_ARGUMENT_ERROR; }
+  *out = pl;
   return ARM_MATH_SUCCESS;
 }
 

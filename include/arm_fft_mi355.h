@@ -345,6 +345,26 @@ arm_status gnss_synth_gps_prn_dev(int32_t prn, float32_t doppler, uint32_t size,
 arm_status gnss_find_top2_peaks_dev(const float32_t *data_dev, int32_t is_complex, int32_t data_size, int32_t pk_sep, uint32_t batch,
                                     gnss_top2 *peaks_dev, void *stream);
 
+/* ---- codes of any length through caller-supplied replicas ----
+ * The fork correlates L5 / E5a codes (10230 chips at 10.23 Msps) by resampling signal and replica
+ * 10230 -> 16384 per millisecond (up_sample_10k_to_16k, CMSIS/CMSIS.cpp:906, :934) and running the same
+ * FFT correlation.  gnss_acq_plan_create_replicas builds a plan from the time-domain replicas
+ * themselves -- n_prn x fft_len complex f32 on the device, one code period at zero Doppler,
+ * zero-padded if samples_per_ms < fft_len -- so any code the caller can produce is searched by the
+ * same fused kernel: gnss_acquire_dev / _groups_dev / gnss_acquire work unchanged on the plan
+ * (signal = n_ms x samples_per_ms complex per scene, sample rate samples_per_ms kHz; prn_labels
+ * only label the result rows).  For L5: gnss_l5_generate_I_dev -> complex (chip, 0) ->
+ * iq_resamp_zero_phase_dev(10230e3, 16384e3, 12, 0.45) -> replicas; the received milliseconds go
+ * through the same resampler call (batch = n_ms).  No counterpart as ONE function in the reference
+ * (its L5 loop is inline in CMSIS.cpp:895-966). */
+arm_status gnss_acq_plan_create_replicas(gnss_acq_plan **plan, uint32_t fft_len, uint32_t samples_per_ms, uint32_t n_ms,
+                                         const float32_t *replicas_dev, const int32_t *prn_labels, uint32_t n_prn,
+                                         const float32_t *dopplers_hz, uint32_t n_dop);
+/* l5_generate_I(prn, out, n_chips, start_at_epoch = true, NULL) (gnss_codes.c:153-204): n_chips chips
+ * (+1 / -1 as int8) of the fork's L5 I-channel generator for PRN 1..37, on the device.  The
+ * registers are not reset at the 10230-chip boundary (as in the reference). */
+arm_status gnss_l5_generate_I_dev(int32_t prn, uint32_t n_chips, int8_t *out_dev);
+
 /* ---- zero-phase I/Q resampler ----
  * Include/gnss_codes.h:97-99, bodies gnss_codes.c:868-904 over iq_resamp_zp_init /
  * iq_resamp_process_zero_phase [Include/up_sample.h:20-24, up_sample.c:31-157].  `in`/`out` are

@@ -174,23 +174,14 @@ int orc_acquire_cell_reference(const orc_c32 *signal, int size, int prn, float d
  *     largest val1 (lowest bin wins ties).
  * Phases are evaluated directly in double (no recursive phasor): the gate downstream is identical
  * PRN / code phase / Doppler bin, not bit-equal correlation values. */
-int orc_acquire_fused(const orc_c32 *signal, int n_ms, int spm, int fft_len, int spc, const int *prns, int n_prn,
-                      const float *dopplers, int n_dop, orc_acq_result *best, orc_acq_result *all)
+/* core: `codes` = n_prn spectra of fft_len points (already transformed), FS = sample rate */
+static int acquire_fused_core(const orc_c32 *signal, int n_ms, int spm, int fft_len, double FS, const orc_c32 *codes, const int *prns,
+                              int n_prn, const float *dopplers, int n_dop, orc_acq_result *best, orc_acq_result *all)
 {
-  if (spm > fft_len || n_ms < 1) return -1;
-  double FS = 1.023e6 * spc;
-  orc_c32 *codes = (orc_c32 *)calloc((size_t)n_prn * fft_len, sizeof(orc_c32));
   orc_c32 *z = (orc_c32 *)malloc(sizeof(orc_c32) * (size_t)fft_len);
   orc_c32 *prod = (orc_c32 *)malloc(sizeof(orc_c32) * (size_t)fft_len);
-  int *chips = (int *)malloc(sizeof(int) * (size_t)(fft_len + spc));
-  if (!codes || !z || !prod || !chips) return -1;
-  for (int p = 0; p < n_prn; p++) {
-    orc_c32 *c = codes + (size_t)p * fft_len;
-    orc_get_code(spm / spc, spc, prns[p], chips);
-    for (int n = 0; n < spm; n++) { c[n].r = (float)chips[n]; c[n].i = 0.0f; }
-    orc_fft_c32(fft_len, c, 1);
-    best[p].peak = -1.0f;
-  }
+  if (!z || !prod) return -1;
+  for (int p = 0; p < n_prn; p++) best[p].peak = -1.0f;
   for (int d = 0; d < n_dop; d++) {
     memset(z, 0, sizeof(orc_c32) * (size_t)fft_len);
     for (int b = 0; b < n_ms; b++) {
@@ -226,10 +217,77 @@ int orc_acquire_fused(const orc_c32 *signal, int n_ms, int spm, int fft_len, int
       if (r.peak > best[p].peak) best[p] = r;
     }
   }
-  free(codes);
   free(z);
   free(prod);
+  return 0;
+}
+
+int orc_acquire_fused(const orc_c32 *signal, int n_ms, int spm, int fft_len, int spc, const int *prns, int n_prn,
+                      const float *dopplers, int n_dop, orc_acq_result *best, orc_acq_result *all)
+{
+  if (spm > fft_len || n_ms < 1) return -1;
+  orc_c32 *codes = (orc_c32 *)calloc((size_t)n_prn * fft_len, sizeof(orc_c32));
+  int *chips = (int *)malloc(sizeof(int) * (size_t)(fft_len + spc));
+  if (!codes || !chips) return -1;
+  for (int p = 0; p < n_prn; p++) {
+    orc_c32 *c = codes + (size_t)p * fft_len;
+    orc_get_code(spm / spc, spc, prns[p], chips);
+    for (int n = 0; n < spm; n++) { c[n].r = (float)chips[n]; c[n].i = 0.0f; }
+    orc_fft_c32(fft_len, c, 1);
+  }
+  int rc = acquire_fused_core(signal, n_ms, spm, fft_len, 1.023e6 * spc, codes, prns, n_prn, dopplers, n_dop, best, all);
+  free(codes);
   free(chips);
+  return rc;
+}
+
+/* The same with caller-supplied time-domain replicas (n_prn x fft_len complex, e.g. an L5 code
+ * resampled 10230 -> 16384 the way CMSIS/CMSIS.cpp:906 prepares it, at zero Doppler); the sample
+ * rate is samples_per_ms kHz. */
+int orc_acquire_fused_replicas(const orc_c32 *signal, int n_ms, int spm, int fft_len, const orc_c32 *replicas, const int *prns, int n_prn,
+                               const float *dopplers, int n_dop, orc_acq_result *best, orc_acq_result *all)
+{
+  if (spm > fft_len || n_ms < 1) return -1;
+  orc_c32 *codes = (orc_c32 *)malloc(sizeof(orc_c32) * (size_t)n_prn * fft_len);
+  if (!codes) return -1;
+  memcpy(codes, replicas, sizeof(orc_c32) * (size_t)n_prn * fft_len);
+  for (int p = 0; p < n_prn; p++) orc_fft_c32(fft_len, codes + (size_t)p * fft_len, 1);
+  int rc = acquire_fused_core(signal, n_ms, spm, fft_len, 1000.0 * spm, codes, prns, n_prn, dopplers, n_dop, best, all);
+  free(codes);
+  return rc;
+}
+
+/* l5_generate_I (gnss_codes.c:153-204) from the epoch: two 13-stage LFSRs, all ones (:147-151),
+ * right shift with the feedback injected at stage 13 (lfsr_step :101-106; g1_feedback :90-94 taps
+ * 13,12,10,9,1; g2_feedback :95-99 taps 13,12,8,7,6,4,3,1), chip = G1 stage 13 XOR two PRN-specific
+ * G2 stages (L5I_TAPS :115-124, stage_bit :130-132), 0 -> +1, 1 -> -1 (:180-181).  The registers
+ * are NOT reset at the 10230-chip boundary (:194-197 only wraps the counter).  Quirk kept: a tap
+ * number 0 makes stage_bit shift by (0 - 1u) = 2^32 - 1, undefined in C; on the x86/ARM hosts the
+ * fork runs on the 32-bit shift count is taken modulo 32, i.e. >> 31, which reads 0 from the
+ * zero-extended 16-bit state -- restated here as "tap 0 contributes 0".  Returns 0, -1 for an
+ * unsupported PRN (:155). */
+static const unsigned char k_l5i_taps[38][2] = {
+    {0, 0},
+    {1, 5}, {2, 6}, {3, 7}, {4, 8}, {0, 8}, {1, 9}, {0, 7}, {1, 8}, {2, 9}, {1, 2},
+    {2, 3}, {4, 5}, {5, 6}, {6, 7}, {7, 8}, {8, 9}, {0, 3}, {1, 4}, {2, 5}, {3, 6},
+    {4, 7}, {5, 8}, {0, 2}, {3, 5}, {4, 6}, {5, 7}, {6, 8}, {7, 9}, {0, 5}, {1, 6},
+    {2, 7}, {3, 8}, {4, 9}, {3, 9}, {0, 6}, {1, 7}, {3, 9},
+};
+int orc_l5_generate_I(int prn, signed char *out, int n)
+{
+  if (prn <= 0 || prn > 37) return -1;
+  unsigned g1 = 0x1FFFu, g2 = 0x1FFFu;
+  const unsigned t1 = k_l5i_taps[prn][0], t2 = k_l5i_taps[prn][1];
+  for (int i = 0; i < n; i++) {
+    unsigned g1_out = (g1 >> 12) & 1u;
+    unsigned a = t1 ? (g2 >> (t1 - 1u)) & 1u : 0u, b = t2 ? (g2 >> (t2 - 1u)) & 1u : 0u;
+    unsigned chip = g1_out ^ a ^ b;
+    out[i] = chip ? -1 : +1;
+    unsigned f1 = ((g1 >> 12) ^ (g1 >> 11) ^ (g1 >> 9) ^ (g1 >> 8) ^ g1) & 1u;
+    unsigned f2 = ((g2 >> 12) ^ (g2 >> 11) ^ (g2 >> 7) ^ (g2 >> 6) ^ (g2 >> 5) ^ (g2 >> 3) ^ (g2 >> 2) ^ g2) & 1u;
+    g1 = ((g1 >> 1) | (f1 << 12)) & 0x1FFFu;
+    g2 = ((g2 >> 1) | (f2 << 12)) & 0x1FFFu;
+  }
   return 0;
 }
 

@@ -403,3 +403,133 @@ def test_grouped_accumulation_errors_and_sharding():
     assert lib.gnss_acquire_groups_dev(*args(2, 1)) == bad          # differential needs two groups
     assert lib.gnss_acquire_groups_dev(pl.p, ctypes.c_void_p(t.data_ptr()), 1, 0, 6, 1, 5, None, ctypes.c_void_p(o.data_ptr()), None, None) == bad
     pl.close()
+
+
+# ------------------------------------------------------------------ 8(f) item 2: L5 codes, 10230 -> 16384 through replicas
+def _l5_code(prn, n=10230):
+    out = np.zeros(n, np.int8)
+    assert H.oracle().orc_l5_generate_I(prn, out.ctypes.data_as(ctypes.c_void_p), n) == 0
+    return out
+
+
+def _resample_10k_to_16k_dev(blocks):
+    """up_sample_10k_to_16k (gnss_codes.c:886-904) on every row of `blocks` [b][10230][2], on the GPU."""
+    import torch
+    import gpu_util as G
+    fa, lib = _lib()
+    blocks = np.ascontiguousarray(blocks, np.float32)
+    b = blocks.shape[0]
+    t, out = _dev(blocks), torch.zeros((b, 16384, 2), dtype=torch.float32, device="cuda")
+    n_out = ctypes.c_uint32(0)
+    G.check(lib.iq_resamp_zero_phase_dev(10230e3, 16384e3, 12, 0.45, ctypes.c_void_p(t.data_ptr()), 10230, ctypes.c_void_p(out.data_ptr()),
+                                         16384, b, ctypes.byref(n_out), G.stream_ptr()))
+    torch.cuda.synchronize()
+    assert n_out.value == 16384
+    return out
+
+
+@pytest.mark.parametrize("prn,n", [(1, 10230), (5, 10230), (23, 64), (37, 12000)])
+def test_l5_generate_I_dev_identical_to_oracle(prn, n):
+    """PRN 5 and 23 have a tap number 0 (reads as 0); 12000 chips run across the 10230 boundary without a reset."""
+    import torch
+    fa, lib = _lib()
+    out = torch.zeros(n, dtype=torch.int8, device="cuda")
+    assert lib.gnss_l5_generate_I_dev(prn, n, ctypes.c_void_p(out.data_ptr())) == 0, fa.last_error()
+    assert np.array_equal(out.cpu().numpy(), _l5_code(prn, n))
+    assert lib.gnss_l5_generate_I_dev(0, n, ctypes.c_void_p(out.data_ptr())) == fa.ARM_MATH_ARGUMENT_ERROR
+    assert lib.gnss_l5_generate_I_dev(38, n, ctypes.c_void_p(out.data_ptr())) == fa.ARM_MATH_ARGUMENT_ERROR
+
+
+def test_l5_acquisition_10230_to_16384_vs_oracle_and_truth():
+    """The fork's L5 flow (CMSIS/CMSIS.cpp:895-966) in the fused form: received milliseconds and code
+    replicas are resampled 10230 -> 16384 (the GPU resampler, checked against the oracle in
+    test_gpu_resamp.py), a plan is built from the replicas, and the fused kernel searches 16384
+    code phases x 9 Doppler bins x 4 PRNs over 4 ms.  Every cell against the oracle on the same
+    resampled arrays; the winners against the truth of the synthetic scene."""
+    import torch
+    import gpu_util as G
+    fa, lib = _lib()
+    L, N, n_ms, fs = 10230, 16384, 4, 10.23e6
+    prns = np.array([3, 5, 17, 30], np.int32)
+    dops = (np.arange(9, dtype=np.float32) - 4) * 250.0
+    # One satellite.  The fork's on-the-fly generator keeps G1 stuck at all ones (five feedback taps on an
+    # all-ones start, gnss_codes.c:90-94), so its "PRNs" are cyclic shifts of ONE m-sequence: the other
+    # replicas see the same satellite at a shifted delay, as they do with the reference's own code.  Real
+    # L5/E5a codes (ICD tables) go through the same replica plan.
+    truth = {3: (2500, 500.0, 1.0)}                                    # prn: (delay in chips, Doppler, amplitude)
+    r = H.rng(0x15)
+    n = np.arange(n_ms * L)
+    sig = r.normal(0, 1.5, (n_ms * L, 2))
+    for prn, (delay, fd, amp) in truth.items():
+        code = _l5_code(prn).astype(np.float64)
+        chips = code[(n - delay) % L]
+        ph = 2 * np.pi * fd * n / fs
+        sig[:, 0] += amp * chips * np.cos(ph)
+        sig[:, 1] += amp * chips * np.sin(ph)
+    sig = sig.astype(np.float32)
+    # replicas: (chip, 0) at 10.23 Msps -> 16384 samples
+    rep_in = np.zeros((len(prns), L, 2), np.float32)
+    for i, prn in enumerate(prns):
+        rep_in[i, :, 0] = _l5_code(int(prn))
+    replicas = _resample_10k_to_16k_dev(rep_in)
+    sig_up = _resample_10k_to_16k_dev(sig.reshape(n_ms, L, 2))          # [n_ms][16384][2] = one scene
+    plan = ctypes.c_void_p()
+    G.check(lib.gnss_acq_plan_create_replicas(ctypes.byref(plan), N, N, n_ms, ctypes.c_void_p(replicas.data_ptr()),
+                                              prns.ctypes.data_as(ctypes.c_void_p), len(prns), dops.ctypes.data_as(ctypes.c_void_p), len(dops)))
+    allc = torch.zeros((len(prns), len(dops), 8), dtype=torch.int32, device="cuda")
+    best = torch.zeros((len(prns), 8), dtype=torch.int32, device="cuda")
+    G.check(lib.gnss_acquire_dev(plan, ctypes.c_void_p(sig_up.data_ptr()), 1, 0, len(dops), ctypes.c_void_p(allc.data_ptr()),
+                                 ctypes.c_void_p(best.data_ptr()), G.stream_ptr()))
+    torch.cuda.synchronize()
+    lib.gnss_acq_plan_destroy(plan)
+    got_all = allc.cpu().numpy().view(H.ACQ_DTYPE).reshape(len(prns), len(dops))
+    got_best = best.cpu().numpy().view(H.ACQ_DTYPE).reshape(len(prns))
+    # oracle on the same resampled arrays
+    want_best, want_all = np.zeros(len(prns), H.ACQ_DTYPE), np.zeros((len(prns), len(dops)), H.ACQ_DTYPE)
+    su, ru = sig_up.cpu().numpy(), replicas.cpu().numpy()
+    assert H.oracle().orc_acquire_fused_replicas(su.ctypes.data_as(ctypes.c_void_p), n_ms, N, N, ru.ctypes.data_as(ctypes.c_void_p),
+                                                 ptr(prns, c_i32), len(prns), ptr(dops, H.c_f), len(dops),
+                                                 want_best.ctypes.data_as(ctypes.c_void_p), want_all.ctypes.data_as(ctypes.c_void_p)) == 0
+    _same_cells(got_all, want_all, "L5 cells")
+    _same_cells(got_best, want_best, "L5 winners")
+    # truth: code phase = delay * 16384 / 10230 (within a sample of the resampled grid), Doppler bin, clear ratio
+    for i, prn in enumerate(prns):
+        row = got_best[i]
+        if int(prn) in truth:
+            delay, fd, _ = truth[int(prn)]
+            assert abs(row["code_phase"] - delay * N / L) <= 1.5, (prn, row)
+            assert dops[row["doppler_bin"]] == fd
+            assert row["peak"] / row["second"] > 1.29                    # the acceptance test of CMSIS.cpp:954
+    # and on into the wire format
+    m = fa.bb_meas_t()
+    n_acc = lib.gnss_acq_to_meas(got_best.ctypes.data_as(ctypes.c_void_p), len(prns), dops.ctypes.data_as(ctypes.c_void_p), len(dops), N,
+                                 1.29, 0.0, fa.SYS_GPS, ctypes.byref(m))
+    assert n_acc >= 1 and 3 in [m.sats[i].prn for i in range(n_acc)]
+    sat = [m.sats[i] for i in range(n_acc) if m.sats[i].prn == 3][0]
+    assert sat.doppler == 500.0 and abs(sat.code_phase * L - 2500) <= 1.0   # code phase in ms -> chips
+
+
+def test_replica_plan_reproduces_the_ca_plan():
+    """A replica plan fed the sample-and-hold C/A codes gives the cells of the built-in GPS plan."""
+    import torch
+    import gpu_util as G
+    fa, lib = _lib()
+    prns, dops = np.array([1, 7, 22], np.int32), (np.arange(5, dtype=np.float32) - 2) * 500.0
+    n_ms, spm, N = 4, 4092, 4096
+    sig = H.make_gps_scene(seed=77, n_ms=n_ms, svs=dict(prns=[7, 22], phases=[300, 2222], dopplers=[500.0, -1000.0]))
+    pl = Plan(N, spm, n_ms, 4, prns, dops)
+    want_best, want_all = pl.acquire_dev(sig)
+    pl.close()
+    rep = np.zeros((len(prns), N, 2), np.float32)
+    for i, prn in enumerate(prns):
+        rep[i, :spm, 0] = H.ca_code(int(prn))        # 1023 chips x 4 samples, sample-and-hold
+    plan = ctypes.c_void_p()
+    t = _dev(rep)
+    G.check(lib.gnss_acq_plan_create_replicas(ctypes.byref(plan), N, spm, n_ms, ctypes.c_void_p(t.data_ptr()),
+                                              prns.ctypes.data_as(ctypes.c_void_p), len(prns), dops.ctypes.data_as(ctypes.c_void_p), len(dops)))
+    s = _dev(np.ascontiguousarray(sig, np.float32))
+    allc = torch.zeros((len(prns), len(dops), 8), dtype=torch.int32, device="cuda")
+    G.check(lib.gnss_acquire_dev(plan, ctypes.c_void_p(s.data_ptr()), 1, 0, len(dops), ctypes.c_void_p(allc.data_ptr()), None, G.stream_ptr()))
+    torch.cuda.synchronize()
+    lib.gnss_acq_plan_destroy(plan)
+    _same_cells(allc.cpu().numpy().view(H.ACQ_DTYPE).reshape(len(prns), len(dops)), want_all[0], "replica plan vs C/A plan")

@@ -127,3 +127,46 @@ def test_config5_scene_truth():
         assert b["peak"] / b["second"] > 1.3 or ph <= b["second_phase"] <= ph + 8
     quiet = [p for p in range(1, 33) if p not in H.GPS_SCENE["prns"]]
     assert max(best[p - 1]["snr_db"] for p in quiet) < min(best[p - 1]["snr_db"] for p in H.GPS_SCENE["prns"])
+
+
+# ------------------------------------------------------------------ 8(f) item 2: the fork's on-the-fly L5 I-code generator
+def _py_l5(prn, n):
+    """Independent restatement of l5_generate_I (gnss_codes.c:153-204) in plain Python."""
+    taps = [(0, 0), (1, 5), (2, 6), (3, 7), (4, 8), (0, 8), (1, 9), (0, 7), (1, 8), (2, 9), (1, 2), (2, 3), (4, 5), (5, 6), (6, 7), (7, 8),
+            (8, 9), (0, 3), (1, 4), (2, 5), (3, 6), (4, 7), (5, 8), (0, 2), (3, 5), (4, 6), (5, 7), (6, 8), (7, 9), (0, 5), (1, 6), (2, 7),
+            (3, 8), (4, 9), (3, 9), (0, 6), (1, 7), (3, 9)]
+    bit = lambda s, k: (s >> (k - 1)) & 1 if k else 0            # stage k; tap number 0 reads as 0 (shift count 2^32 - 1 mod 32)
+    g1 = g2 = 0x1FFF
+    t1, t2 = taps[prn]
+    out = []
+    for _ in range(n):
+        out.append(-1 if (bit(g1, 13) ^ bit(g2, t1) ^ bit(g2, t2)) else 1)
+        f1 = bit(g1, 13) ^ bit(g1, 12) ^ bit(g1, 10) ^ bit(g1, 9) ^ bit(g1, 1)
+        f2 = bit(g2, 13) ^ bit(g2, 12) ^ bit(g2, 8) ^ bit(g2, 7) ^ bit(g2, 6) ^ bit(g2, 4) ^ bit(g2, 3) ^ bit(g2, 1)
+        g1, g2 = (g1 >> 1) | (f1 << 12), (g2 >> 1) | (f2 << 12)
+    return np.array(out, np.int8)
+
+
+@pytest.mark.parametrize("prn", [1, 5, 10, 23, 37])
+def test_l5_generator_matches_independent_restatement(prn):
+    out = np.zeros(10230, np.int8)
+    assert H.oracle().orc_l5_generate_I(prn, out.ctypes.data_as(ctypes.c_void_p), 10230) == 0
+    assert np.array_equal(out, _py_l5(prn, 10230))
+
+
+def test_l5_generator_properties_of_the_reference_as_written():
+    """Parity unpinned by the reference (it holds no L5 vector; its own flow reads the code from a file that is
+    not in the mount).  What the code as written implies: G1 never leaves the all-ones state (five feedback
+    taps on an all-ones start), G2 as wired (right shift, taps 13,12,8,7,6,4,3,1) cycles with period 7665 -- not
+    the 8191 of a maximal register --, nothing resets at chip 10230, unsupported PRNs are refused."""
+    P = 7665
+    out = np.zeros(3 * P, np.int8)
+    assert H.oracle().orc_l5_generate_I(1, out.ctypes.data_as(ctypes.c_void_p), out.size) == 0
+    assert np.array_equal(out[:P], out[P:2 * P]) and np.array_equal(out[:P], out[2 * P:])
+    assert not any(np.array_equal(out[:P], np.roll(out[:P], s)) for s in (1, 2, 3, 7, 511, 2555, 3832))
+    a, b = np.zeros(P, np.int8), np.zeros(P, np.int8)
+    H.oracle().orc_l5_generate_I(17, a.ctypes.data_as(ctypes.c_void_p), P)     # taps (0, 3) -> G2 stage 3 alone
+    H.oracle().orc_l5_generate_I(5, b.ctypes.data_as(ctypes.c_void_p), P)      # taps (0, 8) -> G2 stage 8 = stage 3, 5 chips apart
+    assert np.array_equal(np.roll(a, -5), b) or np.array_equal(np.roll(a, 5), b)
+    assert H.oracle().orc_l5_generate_I(0, a.ctypes.data_as(ctypes.c_void_p), 8) == -1
+    assert H.oracle().orc_l5_generate_I(38, a.ctypes.data_as(ctypes.c_void_p), 8) == -1
