@@ -180,7 +180,7 @@ __device__ __forceinline__ Cand cand_better(Cand a, Cand b)
 
 // T threads, thread tid owns samples [tid*CH, tid*CH + CH) of mag(m) (m < n valid; FULL: n == T*CH).
 // `xch` = LDS scratch of >= 3 * (T/64) * 8 + 16 bytes not aliased with what mag() reads.  All
-// threads return the result.  Branch-free per sample: ~15 VALU operations.
+// threads return the result.
 template <int T, int CH, bool FULL, class Mag>
 __device__ __forceinline__ Top2 top2_scan(Mag mag, int n, int sep, int tid, void *xch)
 {
@@ -188,7 +188,7 @@ __device__ __forceinline__ Top2 top2_scan(Mag mag, int n, int sep, int tid, void
   const int lane = tid & 63, wv = tid >> 6;
   const int m0 = tid * CH;
   float x[CH];
-  PrefixMax loc{kNoPeak, -1};
+  PrefixMax loc{kNoPeak, -1}, prevloc{kNoPeak, -1};  // chunk maximum (last index on ties) and the chunk's state just before it
   float fsum = 0.f;
 #pragma unroll
   for (int c = 0; c < CH; c++) {
@@ -197,6 +197,8 @@ __device__ __forceinline__ Top2 top2_scan(Mag mag, int n, int sep, int tid, void
     x[c] = ok ? mag(m) : kNoPeak;
     fsum += ok ? x[c] : 0.f;
     const bool rec = ok && x[c] >= loc.v;
+    prevloc.v = rec ? loc.v : prevloc.v;
+    prevloc.i = rec ? loc.i : prevloc.i;
     loc.v = rec ? x[c] : loc.v;
     loc.i = rec ? m : loc.i;
   }
@@ -224,21 +226,40 @@ __device__ __forceinline__ Top2 top2_scan(Mag mag, int n, int sep, int tid, void
   }
   PrefixMax run = pm_combine(before, exc);  // state (v1, i1) seen by this thread's first sample
 
-  // walk the chunk: every sample offers at most one candidate
-  Cand best{0.f, 0u};
+  // the candidate sample m offers when the state before it is r (see the rule above)
   const unsigned usep2 = 2u * (unsigned)sep;
+  auto offer = [&](float xv, int m, bool ok, PrefixMax r) -> Cand {
+    const bool rec = ok && xv >= r.v;
+    // |m - r.i| > sep  <=>  (unsigned)(m - r.i + sep) > 2 sep ; r.i == -1 (nothing seen yet) offers nothing
+    const bool far = ((unsigned)(m - r.i + sep) > usep2) && r.i != -1;
+    Cand k;
+    k.v = rec ? r.v : xv;
+    k.ord = rec ? ((1u << 31) | ((unsigned)m << 15) | (unsigned)r.i) : (((unsigned)(32767 - m) << 15) | (unsigned)m);
+    if (!(ok && far)) k.ord = 0u;
+    return k;
+  };
+  // Round 1: only the chunk maximum of every thread offers (its state = the thread's incoming state
+  // advanced over the chunk's earlier samples = prevloc).  The best of these over the WAVE is a real
+  // candidate, so its value L is a lower bound of the final runner-up: a sample below L cannot win
+  // -- as a (B) candidate its value is its own, as an (A) candidate it hands down a record that is
+  // not larger than itself -- and equal values still take part (>=).
+  Cand best = offer(loc.v, loc.i, loc.i != -1, pm_combine(run, prevloc));
+  Cand wbest = best;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    Cand o{__shfl_xor(wbest.v, off), __shfl_xor(wbest.ord, off)};
+    wbest = cand_better(wbest, o);
+  }
+  const float lower = wbest.ord ? wbest.v : -__builtin_huge_valf();
+  // Round 2: walk the chunk; the state advances at every sample (3 operations), the offer is
+  // evaluated only in steps where some lane of the wave holds a sample >= L -- for a noise row
+  // that is a handful of the 16 steps of one or two waves.
 #pragma unroll
   for (int c = 0; c < CH; c++) {
     const int m = m0 + c;
     const bool ok = FULL || m < n;
+    if (__any(ok && x[c] >= lower)) best = cand_better(best, offer(x[c], m, ok, run));
     const bool rec = ok && x[c] >= run.v;
-    // |m - run.i| > sep  <=>  (unsigned)(m - run.i + sep) > 2 sep ; run.i == -1 (nothing seen yet) offers nothing
-    const bool far = ((unsigned)(m - run.i + sep) > usep2) && run.i != -1;
-    Cand k;
-    k.v = rec ? run.v : x[c];
-    k.ord = rec ? ((1u << 31) | ((unsigned)m << 15) | (unsigned)run.i) : (((unsigned)(32767 - m) << 15) | (unsigned)m);
-    if (!(ok && far)) k.ord = 0u;
-    best = cand_better(best, k);
     run.v = rec ? x[c] : run.v;
     run.i = rec ? m : run.i;
   }
