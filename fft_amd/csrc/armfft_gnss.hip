@@ -156,6 +156,18 @@ struct PrefixMax {
 };
 __device__ __forceinline__ PrefixMax pm_combine(PrefixMax earlier, PrefixMax later) { return later.v >= earlier.v ? later : earlier; }
 
+// ---- cross-lane moves without the LDS crossbar (DPP, gfx9): a lane whose source lies outside its
+// row of 16, or that the row mask excludes, keeps `old` ----
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ int dpp_i(int old, int src) { return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, 0xF, false); }
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_f(float old, float src)
+{
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, ROW_MASK, 0xF, false));
+}
+constexpr int kDppShr1 = 0x111, kDppShr2 = 0x112, kDppShr4 = 0x114, kDppShr8 = 0x118, kDppWaveShr1 = 0x138;
+constexpr int kDppBcast15 = 0x142, kDppBcast31 = 0x143, kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppHalfMirror = 0x141, kDppMirror = 0x140;
+
 struct Top2 {
   float v1, v2;
   int i1, i2;
@@ -204,14 +216,18 @@ __device__ __forceinline__ Top2 top2_scan(Mag mag, int n, int sep, int tid, void
   }
   double sum = (double)fsum;
   // inclusive scan of the per-thread maxima over the wave, then over the waves
+  // (DPP: shifts inside the rows of 16 lanes, then the row totals broadcast into the later rows;
+  // a lane without a source receives the identity {kNoPeak, -1}, which pm_combine ignores)
   PrefixMax inc = loc;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    PrefixMax o{__shfl_up(inc.v, off), __shfl_up(inc.i, off)};
-    if (lane >= off) inc = pm_combine(o, inc);
+#define ARMFFT_SCAN_STEP(CTRL, MASK)                                                                   \
+  {                                                                                                    \
+    const PrefixMax o{dpp_f<CTRL, MASK>(kNoPeak, inc.v), dpp_i<CTRL, MASK>(-1, inc.i)};                \
+    inc = pm_combine(o, inc);                                                                          \
   }
-  PrefixMax exc{__shfl_up(inc.v, 1), __shfl_up(inc.i, 1)};
-  if (lane == 0) exc = PrefixMax{kNoPeak, -1};
+  ARMFFT_SCAN_STEP(kDppShr1, 0xF) ARMFFT_SCAN_STEP(kDppShr2, 0xF) ARMFFT_SCAN_STEP(kDppShr4, 0xF) ARMFFT_SCAN_STEP(kDppShr8, 0xF)
+  ARMFFT_SCAN_STEP(kDppBcast15, 0xA) ARMFFT_SCAN_STEP(kDppBcast31, 0xC)
+#undef ARMFFT_SCAN_STEP
+  const PrefixMax exc{dpp_f<kDppWaveShr1>(kNoPeak, inc.v), dpp_i<kDppWaveShr1>(-1, inc.i)};
   PrefixMax *wtot = reinterpret_cast<PrefixMax *>(xch);   // [NW]
   Cand *wcand = reinterpret_cast<Cand *>(wtot + NW);       // [NW]
   double *wsum = reinterpret_cast<double *>(wcand + NW);   // [NW]
@@ -244,12 +260,18 @@ __device__ __forceinline__ Top2 top2_scan(Mag mag, int n, int sep, int tid, void
   // -- as a (B) candidate its value is its own, as an (A) candidate it hands down a record that is
   // not larger than itself -- and equal values still take part (>=).
   Cand best = offer(loc.v, loc.i, loc.i != -1, pm_combine(run, prevloc));
-  Cand wbest = best;
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    Cand o{__shfl_xor(wbest.v, off), __shfl_xor(wbest.ord, off)};
-    wbest = cand_better(wbest, o);
-  }
+  // (butterfly inside the rows by DPP -- cand_better is a maximum over distinct keys, so any
+  // pairing works --, the two cross-row steps through the LDS crossbar)
+  auto wave_best = [](Cand k) -> Cand {
+#define ARMFFT_RED_STEP(CTRL)                                                                                        \
+  k = cand_better(k, Cand{dpp_f<CTRL>(k.v, k.v), (unsigned)dpp_i<CTRL>((int)k.ord, (int)k.ord)});
+    ARMFFT_RED_STEP(kDppXor1) ARMFFT_RED_STEP(kDppXor2) ARMFFT_RED_STEP(kDppHalfMirror) ARMFFT_RED_STEP(kDppMirror)
+#undef ARMFFT_RED_STEP
+    k = cand_better(k, Cand{__shfl_xor(k.v, 16), __shfl_xor(k.ord, 16)});
+    k = cand_better(k, Cand{__shfl_xor(k.v, 32), __shfl_xor(k.ord, 32)});
+    return k;
+  };
+  const Cand wbest = wave_best(best);
   const float lower = wbest.ord ? wbest.v : -__builtin_huge_valf();
   // Round 2: walk the chunk; the state advances at every sample (3 operations), the offer is
   // evaluated only in steps where some lane of the wave holds a sample >= L -- for a noise row
@@ -263,11 +285,19 @@ __device__ __forceinline__ Top2 top2_scan(Mag mag, int n, int sep, int tid, void
     run.v = rec ? x[c] : run.v;
     run.i = rec ? m : run.i;
   }
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    Cand o{__shfl_xor(best.v, off), __shfl_xor(best.ord, off)};
-    best = cand_better(best, o);
-    sum += __shfl_xor(sum, off);
+  best = wave_best(best);
+  {
+    auto dsum_step = [&](auto mover) {
+      const long long bits = __double_as_longlong(sum);
+      const int lo = mover((int)(bits & 0xffffffffll)), hi = mover((int)(bits >> 32));
+      sum += __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+    };
+    dsum_step([](int w) { return dpp_i<kDppXor1>(w, w); });
+    dsum_step([](int w) { return dpp_i<kDppXor2>(w, w); });
+    dsum_step([](int w) { return dpp_i<kDppHalfMirror>(w, w); });
+    dsum_step([](int w) { return dpp_i<kDppMirror>(w, w); });
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
   }
   if (lane == 0) {
     wcand[wv] = best;
