@@ -52,13 +52,13 @@ __device__ __forceinline__ int scrambled_pos(int k)
 struct TuneBase {
   static constexpr unsigned HMASK = 0, LAZYMASK = 0;
   static constexpr int MINW = 4, WGPCU = 0, HP = 0, AUX = 0;
-  static constexpr bool PRE = false, BUF = false, NESTED8 = false;
+  static constexpr bool PRE = false, BUF = false, NESTED8 = false, ONESHOT = false;
 };
 template <int LOGN> struct Tune : TuneBase {};
 template <> struct Tune<11> : TuneBase { static constexpr unsigned HMASK = 6; static constexpr int MINW = 2, WGPCU = 2; };
-template <> struct Tune<12> : TuneBase { static constexpr unsigned LAZYMASK = ~0u; static constexpr int MINW = 2, WGPCU = 2, HP = 0, AUX = 2; static constexpr bool PRE = true, BUF = true; };
-template <> struct Tune<13> : TuneBase { static constexpr unsigned LAZYMASK = ~0u; static constexpr int MINW = 2, WGPCU = 1, HP = 0, AUX = 0; static constexpr bool PRE = true, BUF = true; };
-template <> struct Tune<14> : TuneBase { static constexpr unsigned LAZYMASK = 8; static constexpr int WGPCU = 1, HP = 2, AUX = 2; static constexpr bool PRE = true, BUF = true, NESTED8 = true; };
+template <> struct Tune<12> : TuneBase { static constexpr unsigned LAZYMASK = ~0u; static constexpr int MINW = 4, WGPCU = 0, HP = 0, AUX = 2; static constexpr bool ONESHOT = true; };
+template <> struct Tune<13> : TuneBase { static constexpr unsigned LAZYMASK = ~0u; static constexpr int MINW = 4, WGPCU = 0, HP = 0, AUX = 0; static constexpr bool ONESHOT = true, NESTED8 = true; };
+template <> struct Tune<14> : TuneBase { static constexpr unsigned LAZYMASK = ~0u; static constexpr int MINW = 4, WGPCU = 0, HP = 0, AUX = 2; static constexpr bool ONESHOT = true, NESTED8 = true; };
 
 // Persistent workgroup that fetches its next transform while the current one is in flight
 // (Tune::PRE).  One transform per workgroup round (TPB == 1, g < ngroups == batch): no per-lane
@@ -168,6 +168,35 @@ __global__ __launch_bounds__(Plan<LOGN>::T, Tune<LOGN>::MINW) void cfft_f32_kern
   twr.tw = tw;
   twr.preload(threadIdx.x);
   const uint32_t g0 = blockIdx.x + blockIdx.y * gridDim.x, gstep = gridDim.x * gridDim.y;
+  if constexpr (Tune<LOGN>::ONESHOT) {
+    // one transform per workgroup, no loop: data loads first, then the twiddle bases (they are
+    // needed from pass 1 on), everything through buffer descriptors
+    static_assert(PL::TPB == 1, "one transform per workgroup");
+    if (g0 >= ngroups) return;
+    const int tid = threadIdx.x;
+    float2 *__restrict__ p = data + (size_t)g0 * PL::N;
+    const __amdgpu_buffer_rsrc_t rs = transform_rsrc(p, PL::N * sizeof(float2));
+    float2 v[16];
+    for_each_first_pass_input_split<PL>(tid, [&](int slot, int, int j, int roff) {
+      const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(rs, j * 8, roff * 8, Tune<LOGN>::AUX);
+      float2 x = make_float2(__uint_as_float(w[0]), __uint_as_float(w[1]));
+      if (INV) x.y = -x.y;
+      v[slot] = x;
+    });
+    TwPow<PL, Tune<LOGN>::LAZYMASK, Tune<LOGN>::NESTED8> twp;
+    twp.preload(tw, tid);
+    if (order == 0) {
+      BufferStore<LOGN, INV, 0, Tune<LOGN>::AUX> st{rs, inv_n};
+      fft_block_preloaded<PL, false>(v, lds, twp, tid, st);
+    } else if (order == 1) {
+      BufferStore<LOGN, INV, 1, Tune<LOGN>::AUX> st{rs, inv_n};
+      fft_block_preloaded<PL, false>(v, lds, twp, tid, st);
+    } else {
+      BufferStore<LOGN, INV, 2, Tune<LOGN>::AUX> st{rs, inv_n};
+      fft_block_preloaded<PL, false>(v, lds, twp, tid, st);
+    }
+    return;
+  }
   if constexpr (Tune<LOGN>::PRE) {
     TwPow<PL, Tune<LOGN>::LAZYMASK, Tune<LOGN>::NESTED8> twp;
     twp.preload(tw, threadIdx.x);
