@@ -55,7 +55,10 @@ struct TuneBase {
   static constexpr bool PRE = false, BUF = false, NESTED8 = false, ONESHOT = false;
 };
 template <int LOGN> struct Tune : TuneBase {};
-template <> struct Tune<11> : TuneBase { static constexpr unsigned HMASK = 6; static constexpr int MINW = 2, WGPCU = 2; };
+// (64 ... 512 points: the one-shot buffer path measured 1.2x - 5.5x SLOWER than the plain kernel --
+// several 64..256-byte segments per wave instruction -- and is not used there)
+template <> struct Tune<10> : TuneBase { static constexpr unsigned LAZYMASK = ~0u; static constexpr int MINW = 4, AUX = 2; static constexpr bool ONESHOT = true; };
+template <> struct Tune<11> : TuneBase { static constexpr unsigned LAZYMASK = ~0u; static constexpr int MINW = 3, AUX = 2; static constexpr bool ONESHOT = true; };
 template <> struct Tune<12> : TuneBase { static constexpr unsigned LAZYMASK = ~0u; static constexpr int MINW = 4, WGPCU = 0, HP = 0, AUX = 2; static constexpr bool ONESHOT = true; };
 template <> struct Tune<13> : TuneBase { static constexpr unsigned LAZYMASK = ~0u; static constexpr int MINW = 4, WGPCU = 0, HP = 0, AUX = 0; static constexpr bool ONESHOT = true, NESTED8 = true; };
 template <> struct Tune<14> : TuneBase { static constexpr unsigned LAZYMASK = ~0u; static constexpr int MINW = 4, WGPCU = 0, HP = 0, AUX = 2; static constexpr bool ONESHOT = true, NESTED8 = true; };
@@ -65,6 +68,10 @@ template <> struct Tune<14> : TuneBase { static constexpr unsigned LAZYMASK = ~0
 // guards and no branches between the memory instructions, so the compiler counts outstanding
 // loads and stores exactly and each wait covers only what it needs.
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// Plan of the complex kernel: one-shot sizes below 4096 points use one transform per workgroup too
+// (64 / 128 threads) instead of the default 256 threads with several transforms.
+template <int LOGN> using CPlan = Plan<LOGN, (Tune<LOGN>::ONESHOT && LOGN < 12) ? (1 << LOGN) / 16 : 0>;
 
 // Buffer descriptor over one transform (gfx9 raw buffer: stride 0, range in bytes, 32-bit data
 // format): address = base + scalar offset + per-lane offset, so the 16 legs of a thread share ONE
@@ -81,19 +88,21 @@ struct BufferStore {
   static constexpr bool SPLIT = true;
   __amdgpu_buffer_rsrc_t rsrc;
   float inv_n;
-  __device__ __forceinline__ void operator()(int, int e0, int roff, float2 x) const
+  // t = transform inside the descriptor (0 when it covers one transform); a store past the
+  // descriptor's range (ragged last workgroup) is dropped by the hardware
+  __device__ __forceinline__ void operator()(int t, int e0, int roff, float2 x) const
   {
     if (INV) x = make_float2(x.x * inv_n, -x.y * inv_n);
     u32x2 w;
     w[0] = __float_as_uint(x.x);
     w[1] = __float_as_uint(x.y);
     if constexpr (ORDER == 0) {
-      __builtin_amdgcn_raw_buffer_store_b64(w, rsrc, e0 * 8, roff * 8, AUX);
+      __builtin_amdgcn_raw_buffer_store_b64(w, rsrc, ((t << LOGN) + e0) * 8, roff * 8, AUX);
     } else {
       int e = e0 + roff;
       if (ORDER == 1) e = scrambled_pos<LOGN>(e);
       if (ORDER == 2) e = (int)(__brev((unsigned)e) >> (32 - LOGN));
-      __builtin_amdgcn_raw_buffer_store_b64(w, rsrc, e * 8, 0, AUX);
+      __builtin_amdgcn_raw_buffer_store_b64(w, rsrc, ((t << LOGN) + e) * 8, 0, AUX);
     }
   }
 };
@@ -102,7 +111,7 @@ template <int LOGN, bool INV, int ORDER, class TW>
 __device__ __forceinline__ void cfft_f32_prefetching(float2 *__restrict__ data, float2 *lds, TW &twp, uint32_t ngroups, uint32_t g0,
                                                      uint32_t gstep)
 {
-  using PL = Plan<LOGN>;
+  using PL = CPlan<LOGN>;
   static_assert(PL::TPB == 1, "prefetching kernel: one transform per workgroup");
   constexpr bool BUF = Tune<LOGN>::BUF;
   constexpr uint32_t BYTES = PL::N * sizeof(float2);
@@ -158,10 +167,10 @@ __device__ __forceinline__ void cfft_f32_prefetching(float2 *__restrict__ data, 
 }
 
 template <int LOGN, bool INV>
-__global__ __launch_bounds__(Plan<LOGN>::T, Tune<LOGN>::MINW) void cfft_f32_kernel(float2 *__restrict__ data, const float2 *__restrict__ tw,
+__global__ __launch_bounds__(CPlan<LOGN>::T, Tune<LOGN>::MINW) void cfft_f32_kernel(float2 *__restrict__ data, const float2 *__restrict__ tw,
                                                                                  uint32_t batch, uint32_t ngroups, int order)
 {
-  using PL = Plan<LOGN>;
+  using PL = CPlan<LOGN>;
   extern __shared__ __attribute__((aligned(16))) float2 lds[];
   const float inv_n = 1.0f / (float)PL::N;
   TwRegs<PL, Tune<LOGN>::HMASK> twr;
@@ -169,16 +178,18 @@ __global__ __launch_bounds__(Plan<LOGN>::T, Tune<LOGN>::MINW) void cfft_f32_kern
   twr.preload(threadIdx.x);
   const uint32_t g0 = blockIdx.x + blockIdx.y * gridDim.x, gstep = gridDim.x * gridDim.y;
   if constexpr (Tune<LOGN>::ONESHOT) {
-    // one transform per workgroup, no loop: data loads first, then the twiddle bases (they are
-    // needed from pass 1 on), everything through buffer descriptors
-    static_assert(PL::TPB == 1, "one transform per workgroup");
+    // one group of TPB transforms per workgroup, no loop: data loads first, then the twiddle bases
+    // (needed from pass 1 on), everything through ONE buffer descriptor over the group's valid
+    // transforms -- loads past it read zeros, stores past it are dropped, so the ragged last group
+    // needs no branch
     if (g0 >= ngroups) return;
     const int tid = threadIdx.x;
-    float2 *__restrict__ p = data + (size_t)g0 * PL::N;
-    const __amdgpu_buffer_rsrc_t rs = transform_rsrc(p, PL::N * sizeof(float2));
+    const uint32_t t0 = g0 * PL::TPB;
+    const uint32_t nvalid = batch - t0 < (uint32_t)PL::TPB ? batch - t0 : (uint32_t)PL::TPB;
+    const __amdgpu_buffer_rsrc_t rs = transform_rsrc(data + (size_t)t0 * PL::N, nvalid * PL::N * (uint32_t)sizeof(float2));
     float2 v[16];
-    for_each_first_pass_input_split<PL>(tid, [&](int slot, int, int j, int roff) {
-      const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(rs, j * 8, roff * 8, Tune<LOGN>::AUX);
+    for_each_first_pass_input_split<PL>(tid, [&](int slot, int t, int j, int roff) {
+      const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(rs, ((t << LOGN) + j) * 8, roff * 8, Tune<LOGN>::AUX);
       float2 x = make_float2(__uint_as_float(w[0]), __uint_as_float(w[1]));
       if (INV) x.y = -x.y;
       v[slot] = x;
@@ -527,7 +538,7 @@ static dim3 grid_for(uint32_t ngroups)
 template <int LOGN, bool INV>
 static hipError_t launch_cfft_one(float2 *data, const float2 *tw, uint32_t batch, int order, hipStream_t stream)
 {
-  using PL = Plan<LOGN>;
+  using PL = CPlan<LOGN>;
   static bool attr_done[16] = {false};
   int dev = 0;
   (void)hipGetDevice(&dev);
