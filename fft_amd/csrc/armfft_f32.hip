@@ -29,44 +29,31 @@ __device__ __forceinline__ int scrambled_pos(int k)
   return (d0 << (3 * N8)) | low;
 }
 
-// Per-size tuning (measured on MI355X, tools/fft4096_lab.hip, profiles/r01_lab_*.txt):
-//   HMASK  passes whose twiddles a persistent workgroup keeps in registers (bit p = pass p)
-//   MINW   __launch_bounds__ waves per SIMD (register budget 512/MINW)
-//   WGPCU  persistent workgroups per CU (0 = one workgroup per group of transforms, no loop)
-// 4096 points: the per-transform twiddle loads (30 per thread, L1/L2 hits) cost 20 % of the
-// run time of the non-persistent kernel; with both twiddled passes in registers and 2
-// workgroups per CU the kernel streams at the same rate as a plain in-place copy.
-//   PRE    persistent workgroups fetch their next transform while the current one is in flight:
-//          the loads are issued in pass HP (after its twiddle multiplies), ahead of the current
-//          transform's stores in the memory queues
-//   LAZYMASK  passes whose twiddles come from register-held powers (TwPow) instead of the table
-//   AUX    cache policy of the kernel's HBM accesses: 2 = nt (non-temporal) on loads and stores;
-//          measured per size (A/B on one box): 4096 +5 %, 16384 +3 %, 8192 -1.5 % (left at 0)
-// 8192 points: one workgroup per CU with 256 VGPRs per thread holds the current transform, the
-// whole next one and the twiddle bases; nothing touches vector memory inside the transform, so
-// the prefetch issued in pass 0 stays in flight across all passes (gfx9 has one in-order vmcnt:
-// a twiddle load after it would have to wait for it).
-// 16384 points: 1024 threads cap the kernel at 128 VGPRs (and 144 KiB of LDS at one workgroup per
-// CU); the prefetch fits only in the last pass, table twiddles.  TwPow variants of this size
-// (any HP) spill, and a spilled prefetch register means wait-for-everything right at the load.
+// Per-size tuning (same-box A/B measurements on MI355X; history in DESIGN.md 3.1):
+//   ONESHOT   one transform per workgroup of N/16 threads, no loop: first-pass loads and last-pass
+//             stores through a buffer descriptor (scalar leg offsets, one per-lane offset
+//             register), twiddles from register-held powers (TwPow, LAZYMASK = passes served that
+//             way, NESTED8 = its temp-free radix-8 form).  ~80-126 VGPRs, so 4 workgroups of 4096
+//             points (8 of 2048, 16 of 1024) share a CU and overlap each other's load, compute
+//             and store phases -- measured faster than persistent workgroups that prefetch their
+//             next transform (which need 170-230 VGPRs): 4096 0.85 -> 0.78 ms per 65536.
+//   MINW      __launch_bounds__ waves per SIMD (register budget 512 / MINW)
+//   AUX       cache policy of the HBM accesses: 2 = nt (streamed once) where it measured faster
+// Below 1024 points the plain kernel (256 threads, several transforms per workgroup, table
+// twiddles) already streams at 5.3-5.5 TB/s; the one-shot buffer path measured 1.2x - 5.5x SLOWER
+// there (several 64..256-byte segments per wave instruction) and is not used.
 struct TuneBase {
-  static constexpr unsigned HMASK = 0, LAZYMASK = 0;
-  static constexpr int MINW = 4, WGPCU = 0, HP = 0, AUX = 0;
-  static constexpr bool PRE = false, BUF = false, NESTED8 = false, ONESHOT = false;
+  static constexpr unsigned LAZYMASK = 0;
+  static constexpr int MINW = 4, AUX = 0;
+  static constexpr bool NESTED8 = false, ONESHOT = false;
 };
 template <int LOGN> struct Tune : TuneBase {};
-// (64 ... 512 points: the one-shot buffer path measured 1.2x - 5.5x SLOWER than the plain kernel --
-// several 64..256-byte segments per wave instruction -- and is not used there)
-template <> struct Tune<10> : TuneBase { static constexpr unsigned LAZYMASK = ~0u; static constexpr int MINW = 4, AUX = 2; static constexpr bool ONESHOT = true; };
+template <> struct Tune<10> : TuneBase { static constexpr unsigned LAZYMASK = ~0u; static constexpr int AUX = 2; static constexpr bool ONESHOT = true; };
 template <> struct Tune<11> : TuneBase { static constexpr unsigned LAZYMASK = ~0u; static constexpr int MINW = 3, AUX = 2; static constexpr bool ONESHOT = true; };
-template <> struct Tune<12> : TuneBase { static constexpr unsigned LAZYMASK = ~0u; static constexpr int MINW = 4, WGPCU = 0, HP = 0, AUX = 2; static constexpr bool ONESHOT = true; };
-template <> struct Tune<13> : TuneBase { static constexpr unsigned LAZYMASK = ~0u; static constexpr int MINW = 4, WGPCU = 0, HP = 0, AUX = 0; static constexpr bool ONESHOT = true, NESTED8 = true; };
-template <> struct Tune<14> : TuneBase { static constexpr unsigned LAZYMASK = ~0u; static constexpr int MINW = 4, WGPCU = 0, HP = 0, AUX = 2; static constexpr bool ONESHOT = true, NESTED8 = true; };
+template <> struct Tune<12> : TuneBase { static constexpr unsigned LAZYMASK = ~0u; static constexpr int AUX = 2; static constexpr bool ONESHOT = true; };
+template <> struct Tune<13> : TuneBase { static constexpr unsigned LAZYMASK = ~0u; static constexpr bool ONESHOT = true, NESTED8 = true; };
+template <> struct Tune<14> : TuneBase { static constexpr unsigned LAZYMASK = ~0u; static constexpr int AUX = 2; static constexpr bool ONESHOT = true, NESTED8 = true; };
 
-// Persistent workgroup that fetches its next transform while the current one is in flight
-// (Tune::PRE).  One transform per workgroup round (TPB == 1, g < ngroups == batch): no per-lane
-// guards and no branches between the memory instructions, so the compiler counts outstanding
-// loads and stores exactly and each wait covers only what it needs.
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 // Plan of the complex kernel: one-shot sizes below 4096 points use one transform per workgroup too
@@ -107,65 +94,6 @@ struct BufferStore {
   }
 };
 
-template <int LOGN, bool INV, int ORDER, class TW>
-__device__ __forceinline__ void cfft_f32_prefetching(float2 *__restrict__ data, float2 *lds, TW &twp, uint32_t ngroups, uint32_t g0,
-                                                     uint32_t gstep)
-{
-  using PL = CPlan<LOGN>;
-  static_assert(PL::TPB == 1, "prefetching kernel: one transform per workgroup");
-  constexpr bool BUF = Tune<LOGN>::BUF;
-  constexpr uint32_t BYTES = PL::N * sizeof(float2);
-  const float inv_n = 1.0f / (float)PL::N;
-  float2 v[16];
-  auto fetch = [&](float2 *dst, uint32_t g, int tid) {
-    const float2 *__restrict__ p = data + (size_t)g * PL::N;
-    if constexpr (BUF) {
-      const __amdgpu_buffer_rsrc_t rs = transform_rsrc(p, BYTES);
-      for_each_first_pass_input_split<PL>(tid, [&](int slot, int, int j, int roff) {
-        const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(rs, j * 8, roff * 8, Tune<LOGN>::AUX);
-        float2 x = make_float2(__uint_as_float(w[0]), __uint_as_float(w[1]));
-        if (INV) x.y = -x.y;
-        dst[slot] = x;
-      });
-    } else {
-      for_each_first_pass_input<PL>(tid, [&](int slot, int, int e) {
-        float2 x = p[e];
-        if (INV) x.y = -x.y;
-        dst[slot] = x;
-      });
-    }
-  };
-  if (g0 < ngroups) fetch(v, g0, threadIdx.x);
-  // vmcnt(0): the loop is entered with nothing in flight, so the waits at its top are derived from
-  // the back edge alone (16 loads, then the stores, which may stay in flight into the next round)
-  __builtin_amdgcn_s_waitcnt(0x0F70);
-  for (uint32_t g = g0; g < ngroups; g += gstep) {
-    int tid = threadIdx.x;
-    asm volatile("" : "+v"(tid));
-    twp.pin();
-    float2 *__restrict__ p = data + (size_t)g * PL::N;
-    float2 nx[16];
-    // the last round re-reads its own transform instead of branching around the loads
-    const uint32_t gn = g + gstep < ngroups ? g + gstep : g;
-    auto hook = [&]() { fetch(nx, gn, tid); };
-    if constexpr (BUF) {
-      BufferStore<LOGN, INV, ORDER, Tune<LOGN>::AUX> st{transform_rsrc(p, BYTES), inv_n};
-      fft_block_preloaded<PL, false, Tune<LOGN>::HP>(v, lds, twp, tid, st, hook);
-    } else {
-      auto st = [&](int, int e, float2 x) {
-        if (INV) x = make_float2(x.x * inv_n, -x.y * inv_n);
-        if (ORDER == 1) e = scrambled_pos<LOGN>(e);
-        if (ORDER == 2) e = (int)(__brev((unsigned)e) >> (32 - LOGN));
-        p[e] = x;
-      };
-      fft_block_preloaded<PL, false, Tune<LOGN>::HP>(v, lds, twp, tid, st, hook);
-    }
-#pragma unroll
-    for (int i = 0; i < 16; i++) v[i] = nx[i];
-    __syncthreads();  // the next transform's first LDS write must not overtake this one's last read
-  }
-}
-
 template <int LOGN, bool INV>
 __global__ __launch_bounds__(CPlan<LOGN>::T, Tune<LOGN>::MINW) void cfft_f32_kernel(float2 *__restrict__ data, const float2 *__restrict__ tw,
                                                                                  uint32_t batch, uint32_t ngroups, int order)
@@ -173,10 +101,8 @@ __global__ __launch_bounds__(CPlan<LOGN>::T, Tune<LOGN>::MINW) void cfft_f32_ker
   using PL = CPlan<LOGN>;
   extern __shared__ __attribute__((aligned(16))) float2 lds[];
   const float inv_n = 1.0f / (float)PL::N;
-  TwRegs<PL, Tune<LOGN>::HMASK> twr;
-  twr.tw = tw;
-  twr.preload(threadIdx.x);
-  const uint32_t g0 = blockIdx.x + blockIdx.y * gridDim.x, gstep = gridDim.x * gridDim.y;
+  const TwTable twr{tw};
+  const uint32_t g0 = blockIdx.x + blockIdx.y * gridDim.x;
   if constexpr (Tune<LOGN>::ONESHOT) {
     // one group of TPB transforms per workgroup, no loop: data loads first, then the twiddle bases
     // (needed from pass 1 on), everything through ONE buffer descriptor over the group's valid
@@ -206,15 +132,6 @@ __global__ __launch_bounds__(CPlan<LOGN>::T, Tune<LOGN>::MINW) void cfft_f32_ker
       BufferStore<LOGN, INV, 2, Tune<LOGN>::AUX> st{rs, inv_n};
       fft_block_preloaded<PL, false>(v, lds, twp, tid, st);
     }
-    return;
-  }
-  if constexpr (Tune<LOGN>::PRE) {
-    TwPow<PL, Tune<LOGN>::LAZYMASK, Tune<LOGN>::NESTED8> twp;
-    twp.preload(tw, threadIdx.x);
-    // output order resolved once per launch, not per store: no branches between the stores
-    if (order == 0) cfft_f32_prefetching<LOGN, INV, 0>(data, lds, twp, ngroups, g0, gstep);
-    else if (order == 1) cfft_f32_prefetching<LOGN, INV, 1>(data, lds, twp, ngroups, g0, gstep);
-    else cfft_f32_prefetching<LOGN, INV, 2>(data, lds, twp, ngroups, g0, gstep);
     return;
   }
   if constexpr (LOGN <= 5) {
@@ -251,10 +168,9 @@ __global__ __launch_bounds__(CPlan<LOGN>::T, Tune<LOGN>::MINW) void cfft_f32_ker
     }
     return;
   }
-  for (uint32_t g = g0; g < ngroups; g += gstep) {
-    int tid = threadIdx.x;
-    if (Tune<LOGN>::WGPCU) asm volatile("" : "+v"(tid));  // keep per-thread address math inside the loop
-    const uint32_t t0 = g * PL::TPB;
+  if (g0 < ngroups) {
+    const int tid = threadIdx.x;
+    const uint32_t t0 = g0 * PL::TPB;
     float2 *__restrict__ p = data + (size_t)t0 * PL::N;     // uniform base, 32-bit per-lane offsets
     auto ld = [&](int t, int e) -> float2 {
       float2 v = make_float2(0.f, 0.f);
@@ -269,8 +185,6 @@ __global__ __launch_bounds__(CPlan<LOGN>::T, Tune<LOGN>::MINW) void cfft_f32_ker
       if (t0 + t < batch) p[t * PL::N + e] = v;
     };
     fft_block_tw<PL, false, false>(lds, twr, tid, ld, st);
-    if (Tune<LOGN>::WGPCU == 0) break;
-    __syncthreads();  // the next transform's first LDS write must not overtake this one's last read
   }
 }
 
@@ -278,131 +192,90 @@ __global__ __launch_bounds__(CPlan<LOGN>::T, Tune<LOGN>::MINW) void cfft_f32_ker
 // LOGM = log2(N/2).  Forward: z = FFT(x as N/2 complex) to LDS, then the split of stage_rfft_f32
 // (arm_rfft_fast_f32.c:316-402).  Inverse: merge_rfft_f32 (:405-462) fused into the load of the
 // inverse complex FFT.
-// Per-size tuning of the real-FFT kernel (LOGM = log2 of the complex length N/2): sizes whose
-// workgroup holds exactly one transform run persistent, prefetching workgroups like the complex
-// kernel (TwPow twiddles, buffer addressing), with the thread-constant split/merge factors kept
-// in registers across transforms.
-// 1024 and 2048 complex points: small workgroups of one transform each (64 / 128 threads) so that
-// the same persistent structure applies; 8 / 4 of them per CU.
-template <int LOGM> struct RTune { static constexpr int MINW = 4, WGPCU = 0, AUX = 0; static constexpr bool NESTED8 = false; };
-template <> struct RTune<10> { static constexpr int MINW = 2, WGPCU = 8, AUX = 2; static constexpr bool NESTED8 = false; };
-template <> struct RTune<11> { static constexpr int MINW = 2, WGPCU = 4, AUX = 0; static constexpr bool NESTED8 = false; };
-template <> struct RTune<12> { static constexpr int MINW = 2, WGPCU = 2, AUX = 2; static constexpr bool NESTED8 = false; };
-template <> struct RTune<13> { static constexpr int MINW = 2, WGPCU = 1, AUX = 0; static constexpr bool NESTED8 = true; };
+// Per-size tuning of the real-FFT kernel (LOGM = log2 of the complex length N/2): from 1024 complex
+// points on, one transform per workgroup of M/16 threads in the one-shot form of the complex
+// kernel (TwPow, buffer addressing, nt policy); below, the plain kernel.
+template <int LOGM> struct RTune { static constexpr int MINW = 4, AUX = 0; static constexpr bool NESTED8 = false, ONESHOT = false; };
+template <> struct RTune<10> { static constexpr int MINW = 4, AUX = 2; static constexpr bool NESTED8 = false, ONESHOT = true; };
+template <> struct RTune<11> { static constexpr int MINW = 4, AUX = 2; static constexpr bool NESTED8 = false, ONESHOT = true; };
+template <> struct RTune<12> { static constexpr int MINW = 4, AUX = 2; static constexpr bool NESTED8 = false, ONESHOT = true; };
+template <> struct RTune<13> { static constexpr int MINW = 4, AUX = 2; static constexpr bool NESTED8 = true, ONESHOT = true; };
 
 template <int LOGM> using RPlan = Plan<LOGM, (LOGM == 10 || LOGM == 11) ? (1 << LOGM) / 16 : 0>;
 
+// One transform per workgroup, no loop (RTune::ONESHOT).  Forward: every thread splits exactly the
+// 16 bins its own last pass produced, so Z[k] never leaves its registers and only Z[M-k] is read
+// back from LDS; the split factors are fetched before the transform.  Inverse: bins k and M-k are
+// loaded raw (the mirrored one at a descending scalar offset) and merged in registers.
 template <int LOGM, bool INV>
-__device__ __forceinline__ void rfft_f32_prefetching(const float2 *__restrict__ in, float2 *__restrict__ out, float2 *lds,
-                                                     const float2 *__restrict__ tw, const float2 *__restrict__ twr, uint32_t ngroups,
-                                                     uint32_t g0, uint32_t gstep)
+__device__ __forceinline__ void rfft_f32_oneshot(const float2 *__restrict__ in, float2 *__restrict__ out, float2 *lds,
+                                                 const float2 *__restrict__ tw, const float2 *__restrict__ twr, uint32_t g)
 {
   using PL = RPlan<LOGM>;
-  static_assert(PL::TPB == 1, "prefetching kernel: one transform per workgroup");
+  static_assert(PL::TPB == 1, "one transform per workgroup");
   constexpr int M = PL::N;
   constexpr uint32_t BYTES = M * sizeof(float2);
-  TwPow<PL, ~0u, RTune<LOGM>::NESTED8> twp;
-  twp.preload(tw, threadIdx.x);
   constexpr int AUX = RTune<LOGM>::AUX;
+  const int tid = threadIdx.x;
   auto load2 = [](const __amdgpu_buffer_rsrc_t &rs, int voff, int soff) -> float2 {
     const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, AUX);
     return make_float2(__uint_as_float(w[0]), __uint_as_float(w[1]));
   };
+  const __amdgpu_buffer_rsrc_t ri = transform_rsrc(in + (size_t)g * M, BYTES);
+  const __amdgpu_buffer_rsrc_t ro = transform_rsrc(out + (size_t)g * M, BYTES);
+  TwPow<PL, ~0u, RTune<LOGM>::NESTED8> twp;
   if constexpr (!INV) {
-    // split factors (sin, cos) of the 16 bins this thread's last pass produces: the thread splits
-    // exactly those, so its own Z[k] never leaves its registers and only Z[M-k] comes from LDS
-    float2 csr[16];
-    for_each_last_pass_output<PL>(threadIdx.x, [&](int slot, int, int e0, int roff) { csr[slot] = twr[e0 + roff]; });
-    auto fetch = [&](float2 *dst, uint32_t g, int tid) {
-      const __amdgpu_buffer_rsrc_t rs = transform_rsrc(in + (size_t)g * M, BYTES);
-      for_each_first_pass_input_split<PL>(tid, [&](int slot, int, int j, int roff) { dst[slot] = load2(rs, j * 8, roff * 8); });
-    };
     float2 v[16];
-    if (g0 < ngroups) fetch(v, g0, threadIdx.x);
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // see cfft_f32_prefetching
-    for (uint32_t g = g0; g < ngroups; g += gstep) {
-      int tid = threadIdx.x;
-      asm volatile("" : "+v"(tid));
-      twp.pin();
-      float2 nx[16];
-      const uint32_t gn = g + gstep < ngroups ? g + gstep : g;
-      auto hook = [&]() { fetch(nx, gn, tid); };
-      auto st = [&](int t, int e, float2 x) { lds[PL::idx(t, e)] = x; };
-      fft_block_preloaded<PL, true, 0>(v, lds, twp, tid, st, hook);
-      __syncthreads();
-      // split: bin k from Z[k] (still in v[]) and Z[M-k]
-      const __amdgpu_buffer_rsrc_t ro = transform_rsrc(out + (size_t)g * M, BYTES);
-      for_each_last_pass_output<PL>(tid, [&](int slot, int, int e0, int roff) {
-        const int k = e0 + roff;
-        const float2 A = v[slot];
-        const float2 B = lds[PL::idx(0, (M - k) & (M - 1))];
-        const float2 c = csr[slot];  // (sin, cos)
-        const float a = B.x - A.x, b = B.y + A.y;
-        float2 o;
-        o.x = 0.5f * (A.x + B.x + c.x * a + c.y * b);
-        o.y = 0.5f * (A.y - B.y + c.y * a - c.x * b);
-        if (k == 0) o = make_float2(A.x + A.y, A.x - A.y);  // 0.5*((2 re) +- (2 im)), exact
-        u32x2 w;
-        w[0] = __float_as_uint(o.x);
-        w[1] = __float_as_uint(o.y);
-        __builtin_amdgcn_raw_buffer_store_b64(w, ro, e0 * 8, roff * 8, AUX);
-        // four bins at a time: hoisting all 16 LDS reads costs more registers than the kernel has
-        if ((slot & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-      });
-#pragma unroll
-      for (int i = 0; i < 16; i++) v[i] = nx[i];
-      __syncthreads();  // the next transform's first LDS write must not overtake the split's reads
-    }
+    for_each_first_pass_input_split<PL>(tid, [&](int slot, int, int j, int roff) { v[slot] = load2(ri, j * 8, roff * 8); });
+    twp.preload(tw, tid);
+    float2 csr[16];  // split factors (sin, cos) of the 16 bins this thread's last pass produces
+    for_each_last_pass_output<PL>(tid, [&](int slot, int, int e0, int roff) { csr[slot] = twr[e0 + roff]; });
+    auto st = [&](int t, int e, float2 x) { lds[PL::idx(t, e)] = x; };
+    fft_block_preloaded<PL, true>(v, lds, twp, tid, st);
+    __syncthreads();
+    // split: bin k from Z[k] (still in v[]) and Z[M-k]
+    for_each_last_pass_output<PL>(tid, [&](int slot, int, int e0, int roff) {
+      const int k = e0 + roff;
+      const float2 A = v[slot];
+      const float2 B = lds[PL::idx(0, (M - k) & (M - 1))];
+      const float2 c = csr[slot];
+      const float a = B.x - A.x, b = B.y + A.y;
+      float2 o;
+      o.x = 0.5f * (A.x + B.x + c.x * a + c.y * b);
+      o.y = 0.5f * (A.y - B.y + c.y * a - c.x * b);
+      if (k == 0) o = make_float2(A.x + A.y, A.x - A.y);  // 0.5*((2 re) +- (2 im)), exact
+      u32x2 w;
+      w[0] = __float_as_uint(o.x);
+      w[1] = __float_as_uint(o.y);
+      __builtin_amdgcn_raw_buffer_store_b64(w, ro, e0 * 8, roff * 8, AUX);
+      if ((slot & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    });
   } else {
-    // merge factors of this thread's 16 first-pass inputs e = j + roff, and the mirrored bins'
-    // per-lane offset: (M - e) * 8 = (M - j - 15 S) * 8 + (15 - r) S * 8 with S = M / 16 (first pass
-    // radix 16: TPB == 1 implies LOGM >= 12), always >= 0; e == 0 reads one element past the end,
-    // which a buffer load returns as zero and the e == 0 branch does not use
     static_assert(PL::lr(0) == 4, "first pass of radix 16");
     constexpr int S = M / 16;
-    float2 cm[16];
-    for_each_first_pass_input_split<PL>(threadIdx.x, [&](int slot, int, int j, int roff) { cm[slot] = twr[j + roff]; });
-    auto fetch = [&](float2 *a, float2 *b, uint32_t g, int tid) {
-      const __amdgpu_buffer_rsrc_t rs = transform_rsrc(in + (size_t)g * M, BYTES);
-      for_each_first_pass_input_split<PL>(tid, [&](int slot, int, int j, int roff) {
-        a[slot] = load2(rs, j * 8, roff * 8);
-        b[slot] = load2(rs, (M - j - 15 * S) * 8, (15 * S - roff) * 8);
-      });
-    };
-    float2 A[16], B[16];
-    if (g0 < ngroups) fetch(A, B, g0, threadIdx.x);
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    const float inv_m = 1.0f / (float)M;
-    for (uint32_t g = g0; g < ngroups; g += gstep) {
-      int tid = threadIdx.x;
-      asm volatile("" : "+v"(tid));
-      twp.pin();
-      float2 v[16];
-      for_each_first_pass_input_split<PL>(tid, [&](int slot, int, int j, int roff) {
-        const float2 a2 = A[slot], b2 = B[slot], c = cm[slot];
-        float2 o;
-        if ((j | roff) == 0) {
-          o = make_float2(0.5f * (a2.x + a2.y), 0.5f * (a2.x - a2.y));
-        } else {
-          const float a = a2.x - b2.x, b = a2.y + b2.y;
-          o.x = 0.5f * (a2.x + b2.x - c.x * a - c.y * b);
-          o.y = 0.5f * (a2.y - b2.y + c.y * a - c.x * b);
-        }
-        o.y = -o.y;  // conjugate in (inverse through the forward kernel)
-        v[slot] = o;
-      });
-      float2 nA[16], nB[16];
-      const uint32_t gn = g + gstep < ngroups ? g + gstep : g;
-      auto hook = [&]() { fetch(nA, nB, gn, tid); };
-      BufferStore<LOGM, true, 0, AUX> st{transform_rsrc(out + (size_t)g * M, BYTES), inv_m};
-      fft_block_preloaded<PL, false, 0>(v, lds, twp, tid, st, hook);
-#pragma unroll
-      for (int i = 0; i < 16; i++) {
-        A[i] = nA[i];
-        B[i] = nB[i];
+    float2 A[16], B[16], cm[16];
+    for_each_first_pass_input_split<PL>(tid, [&](int slot, int, int j, int roff) {
+      A[slot] = load2(ri, j * 8, roff * 8);
+      B[slot] = load2(ri, (M - j - 15 * S) * 8, (15 * S - roff) * 8);   // bin M - e; e == 0 reads past the end: zero, unused
+    });
+    for_each_first_pass_input_split<PL>(tid, [&](int slot, int, int j, int roff) { cm[slot] = twr[j + roff]; });
+    twp.preload(tw, tid);
+    float2 v[16];
+    for_each_first_pass_input_split<PL>(tid, [&](int slot, int, int j, int roff) {
+      const float2 a2 = A[slot], b2 = B[slot], c = cm[slot];
+      float2 o;
+      if ((j | roff) == 0) {
+        o = make_float2(0.5f * (a2.x + a2.y), 0.5f * (a2.x - a2.y));
+      } else {
+        const float a = a2.x - b2.x, b = a2.y + b2.y;
+        o.x = 0.5f * (a2.x + b2.x - c.x * a - c.y * b);
+        o.y = 0.5f * (a2.y - b2.y + c.y * a - c.x * b);
       }
-      __syncthreads();
-    }
+      o.y = -o.y;  // conjugate in (inverse through the forward kernel)
+      v[slot] = o;
+    });
+    BufferStore<LOGM, true, 0, AUX> st{ro, 1.0f / (float)M};
+    fft_block_preloaded<PL, false>(v, lds, twp, tid, st);
   }
 }
 
@@ -414,8 +287,9 @@ __global__ __launch_bounds__(RPlan<LOGM>::T, RTune<LOGM>::MINW) void rfft_f32_ke
   using PL = RPlan<LOGM>;
   constexpr int M = PL::N;
   extern __shared__ __attribute__((aligned(16))) float2 lds[];
-  if constexpr (RTune<LOGM>::WGPCU > 0) {
-    rfft_f32_prefetching<LOGM, INV>(in, out, lds, tw, twr, ngroups, blockIdx.x + blockIdx.y * gridDim.x, gridDim.x * gridDim.y);
+  if constexpr (RTune<LOGM>::ONESHOT) {
+    const uint32_t g = blockIdx.x + blockIdx.y * gridDim.x;
+    if (g < ngroups) rfft_f32_oneshot<LOGM, INV>(in, out, lds, tw, twr, g);
     return;
   }
   const int tid = threadIdx.x;
@@ -516,18 +390,6 @@ hipError_t launch_gen_twiddle_rfft(float2 *tw, uint32_t n_real, hipStream_t stre
 }
 
 // ---- launchers ----
-static int cu_count(int dev)
-{
-  static int cus[16] = {0};
-  if (dev < 0 || dev >= 16) return 256;
-  if (!cus[dev]) {
-    int n = 0;
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    cus[dev] = n;
-  }
-  return cus[dev];
-}
-
 static dim3 grid_for(uint32_t ngroups)
 {
   // one workgroup per group of TPB transforms; fold very large batches into grid.y
@@ -550,10 +412,6 @@ static hipError_t launch_cfft_one(float2 *data, const float2 *tw, uint32_t batch
   }
   const uint32_t ngroups = (batch + PL::TPB - 1) / PL::TPB;
   dim3 grid = grid_for(ngroups);
-  if (Tune<LOGN>::WGPCU) {
-    const uint32_t resident = (uint32_t)Tune<LOGN>::WGPCU * (uint32_t)cu_count(dev);
-    if (ngroups > resident) grid = dim3(resident, 1, 1);
-  }
   kern<<<grid, PL::T, PL::LDS_BYTES, stream>>>(data, tw, batch, ngroups, order);
   return hipGetLastError();
 }
@@ -587,10 +445,6 @@ static hipError_t launch_rfft_one(const float2 *in, float2 *out, const float2 *t
   }
   const uint32_t ngroups = (batch + PL::TPB - 1) / PL::TPB;
   dim3 grid = grid_for(ngroups);
-  if (RTune<LOGM>::WGPCU) {
-    const uint32_t resident = (uint32_t)RTune<LOGM>::WGPCU * (uint32_t)cu_count(dev);
-    if (ngroups > resident) grid = dim3(resident, 1, 1);
-  }
   kern<<<grid, PL::T, PL::LDS_BYTES, stream>>>(in, out, tw, twr, batch, ngroups);
   return hipGetLastError();
 }
