@@ -355,3 +355,25 @@ def test_cfft_q15_4096_many_rounds_bit_exact(ifft):
     assert H.oracle().orc_cfft_q15_batch(ptr(want, c_i16), n, batch, ifft, 1, 0) == 0
     got = G.cfft_dev("q15", x, n, ifft)
     assert np.array_equal(got, want)
+
+
+def test_cfft_f32_more_groups_than_one_grid_row():
+    """More than 65536 workgroups fold into grid.y (one-shot kernels: one transform per workgroup):
+    first, last and a few transforms in between against the oracle; Parseval on all."""
+    import torch
+    import fft_amd
+    G = _gpu()
+    n, batch = 1024, 70001
+    g = torch.Generator(device="cuda").manual_seed(0x5EED0077)
+    x = (torch.rand((batch, 2 * n), device="cuda", generator=g) * 2 - 1).contiguous()
+    y = x.clone()
+    S = G.cfft_inst("f32", n)
+    G.check(fft_amd.lib.arm_cfft_f32_dev(ctypes.byref(S), ctypes.c_void_p(y.data_ptr()), batch, 0, 1, G.stream_ptr()))
+    torch.cuda.synchronize()
+    ex = (x.double() ** 2).sum(dim=1)
+    ey = (y.double() ** 2).sum(dim=1) / n
+    assert float(((ex - ey).abs() / ex).max()) < 1e-5
+    idx = [0, 1, 65535, 65536, 65537, batch - 1]
+    sub = x[idx].cpu().numpy().copy()
+    assert H.oracle().orc_cfft_f32_batch(ptr(sub, c_f), n, len(idx), 0, 1) == 0
+    assert H.rel_l2(y[idx].cpu().numpy(), sub) <= 5e-7
