@@ -39,15 +39,22 @@ __device__ __forceinline__ int scrambled_pos(int k)
 //             next transform (which need 170-230 VGPRs): 4096 0.85 -> 0.78 ms per 65536.
 //   MINW      __launch_bounds__ waves per SIMD (register budget 512 / MINW)
 //   AUX       cache policy of the HBM accesses: 2 = nt (streamed once) where it measured faster
-// Below 1024 points the plain kernel (256 threads, several transforms per workgroup, table
-// twiddles) already streams at 5.3-5.5 TB/s; the one-shot buffer path measured 1.2x - 5.5x SLOWER
-// there (several 64..256-byte segments per wave instruction) and is not used.
+// 256 and 512 points run the one-shot path in ONE wave (64 threads, 4 / 2 transforms): every wave
+// instruction then touches whole 128-byte lines (256) or one 512-byte run (512), so nt applies:
+// 5.4 -> 5.8 TB/s and 5.3 -> 5.9 TB/s.  64 and 128 points stay on the plain kernel (256 threads,
+// several transforms per workgroup, table twiddles; 5.25 / 5.5 TB/s): there a wave instruction
+// covers 32/64-byte segments, nt costs 15%, the one-shot form without nt and LDS staging measured
+// the same or slower.  16 and 32 points are staged through LDS with 16-byte accesses (nt pays at
+// 16 points only: 5.48 -> 5.67 TB/s).
 struct TuneBase {
   static constexpr unsigned LAZYMASK = 0;
   static constexpr int MINW = 4, AUX = 0;
   static constexpr bool NESTED8 = false, ONESHOT = false;
 };
 template <int LOGN> struct Tune : TuneBase {};
+template <> struct Tune<4> : TuneBase { static constexpr int AUX = 2; };
+template <> struct Tune<8> : TuneBase { static constexpr unsigned LAZYMASK = ~0u; static constexpr int AUX = 2; static constexpr bool ONESHOT = true; };
+template <> struct Tune<9> : TuneBase { static constexpr unsigned LAZYMASK = ~0u; static constexpr int AUX = 2; static constexpr bool ONESHOT = true; };
 template <> struct Tune<10> : TuneBase { static constexpr unsigned LAZYMASK = ~0u; static constexpr int AUX = 2; static constexpr bool ONESHOT = true; };
 template <> struct Tune<11> : TuneBase { static constexpr unsigned LAZYMASK = ~0u; static constexpr int MINW = 3, AUX = 2; static constexpr bool ONESHOT = true; };
 template <> struct Tune<12> : TuneBase { static constexpr unsigned LAZYMASK = ~0u; static constexpr int AUX = 2; static constexpr bool ONESHOT = true; };
@@ -56,9 +63,11 @@ template <> struct Tune<14> : TuneBase { static constexpr unsigned LAZYMASK = ~0
 
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-// Plan of the complex kernel: one-shot sizes below 4096 points use one transform per workgroup too
-// (64 / 128 threads) instead of the default 256 threads with several transforms.
-template <int LOGN> using CPlan = Plan<LOGN, (Tune<LOGN>::ONESHOT && LOGN < 12) ? (1 << LOGN) / 16 : 0>;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Plan of the complex kernel: one-shot sizes below 4096 points use N/16 threads (at least one
+// wave: 256 and 512 points put 4 / 2 transforms in it) instead of the default 256 threads.
+template <int LOGN> using CPlan = Plan<LOGN, (Tune<LOGN>::ONESHOT && LOGN < 12) ? ((1 << LOGN) / 16 < 64 ? 64 : (1 << LOGN) / 16) : 0>;
 
 // Buffer descriptor over one transform (gfx9 raw buffer: stride 0, range in bytes, 32-bit data
 // format): address = base + scalar offset + per-lane offset, so the 16 legs of a thread share ONE
@@ -148,7 +157,7 @@ __global__ __launch_bounds__(CPlan<LOGN>::T, Tune<LOGN>::MINW) void cfft_f32_ker
     for (int i = tid; i < PAIRS; i += PL::T) {
       const int e2 = 2 * i, t = e2 >> LOGN, e = e2 & (PL::N - 1);
       float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-      if ((uint32_t)e2 < nvalid) x = *reinterpret_cast<const float4 *>(p + e2);
+      if ((uint32_t)e2 < nvalid) { if (Tune<LOGN>::AUX == 2) { const f32x4 y = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p + e2)); x = make_float4(y[0], y[1], y[2], y[3]); } else x = *reinterpret_cast<const float4 *>(p + e2); }
       if (INV) { x.y = -x.y; x.w = -x.w; }
       *reinterpret_cast<float4 *>(&lds[PL::idx(t, e)]) = x;
     }
@@ -164,7 +173,7 @@ __global__ __launch_bounds__(CPlan<LOGN>::T, Tune<LOGN>::MINW) void cfft_f32_ker
     __syncthreads();
     for (int i = tid; i < PAIRS; i += PL::T) {
       const int e2 = 2 * i, t = e2 >> LOGN, e = e2 & (PL::N - 1);
-      if ((uint32_t)e2 < nvalid) *reinterpret_cast<float4 *>(p + e2) = *reinterpret_cast<const float4 *>(&lds[PL::idx(t, e)]);
+      if ((uint32_t)e2 < nvalid) { const float4 y = *reinterpret_cast<const float4 *>(&lds[PL::idx(t, e)]); if (Tune<LOGN>::AUX == 2) { f32x4 z; z[0] = y.x; z[1] = y.y; z[2] = y.z; z[3] = y.w; __builtin_nontemporal_store(z, reinterpret_cast<f32x4 *>(p + e2)); } else *reinterpret_cast<float4 *>(p + e2) = y; }
     }
     return;
   }
