@@ -801,6 +801,10 @@ arm_status arm_cfft_u32_f32_dev(const arm_cfft_instance_u32_f32 *S, float32_t *p
 arm_status arm_cfft_u32_batch_f32(const arm_cfft_instance_u32_f32 *S, float32_t *p, uint32_t batch, uint8_t ifft)
 {
   if (!S || !p) { set_error("arm_cfft_u32_batch_f32: null argument"); return ARM_MATH_ARGUMENT_ERROR; }
+  if (!is_pow2(S->fftLen) || ilog2u(S->fftLen) < kMinLog || ilog2u(S->fftLen) > kMaxLargeLog) {
+    set_error("arm_cfft_u32_batch_f32: unsupported fftLen %u", S->fftLen);  // before any staging is sized from it
+    return ARM_MATH_ARGUMENT_ERROR;
+  }
   if (batch == 0) return ARM_MATH_SUCCESS;
   int dev;
   if (!current_device(&dev)) return ARM_MATH_ARGUMENT_ERROR;
