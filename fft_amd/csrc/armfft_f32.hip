@@ -201,16 +201,20 @@ __global__ __launch_bounds__(CPlan<LOGN>::T, Tune<LOGN>::MINW) void cfft_f32_ker
 // LOGM = log2(N/2).  Forward: z = FFT(x as N/2 complex) to LDS, then the split of stage_rfft_f32
 // (arm_rfft_fast_f32.c:316-402).  Inverse: merge_rfft_f32 (:405-462) fused into the load of the
 // inverse complex FFT.
-// Per-size tuning of the real-FFT kernel (LOGM = log2 of the complex length N/2): from 1024 complex
-// points on, one transform per workgroup of M/16 threads in the one-shot form of the complex
-// kernel (TwPow, buffer addressing, nt policy); below, the plain kernel.
+// Per-size tuning of the real-FFT kernel (LOGM = log2 of the complex length N/2): from 256 complex
+// points on, the one-shot form of the complex kernel (TwPow, buffer addressing, nt policy) -- one
+// transform per workgroup of M/16 threads from 1024 on, 4 / 2 transforms in one wave at 256 / 512
+// (512 real points 5.0 -> 5.45 TB/s, 1024: 4.5 -> 5.48); below, the plain kernel.  (Staging the
+// 32-point case through LDS like the 16-point complex kernel measured no gain: 3.7 TB/s both ways.)
 template <int LOGM> struct RTune { static constexpr int MINW = 4, AUX = 0; static constexpr bool NESTED8 = false, ONESHOT = false; };
+template <> struct RTune<8> { static constexpr int MINW = 4, AUX = 2; static constexpr bool NESTED8 = false, ONESHOT = true; };
+template <> struct RTune<9> { static constexpr int MINW = 4, AUX = 2; static constexpr bool NESTED8 = false, ONESHOT = true; };
 template <> struct RTune<10> { static constexpr int MINW = 4, AUX = 2; static constexpr bool NESTED8 = false, ONESHOT = true; };
 template <> struct RTune<11> { static constexpr int MINW = 4, AUX = 2; static constexpr bool NESTED8 = false, ONESHOT = true; };
 template <> struct RTune<12> { static constexpr int MINW = 4, AUX = 2; static constexpr bool NESTED8 = false, ONESHOT = true; };
 template <> struct RTune<13> { static constexpr int MINW = 4, AUX = 2; static constexpr bool NESTED8 = true, ONESHOT = true; };
 
-template <int LOGM> using RPlan = Plan<LOGM, (LOGM == 10 || LOGM == 11) ? (1 << LOGM) / 16 : 0>;
+template <int LOGM> using RPlan = Plan<LOGM, (LOGM == 8 || LOGM == 9) ? 64 : (LOGM == 10 || LOGM == 11) ? (1 << LOGM) / 16 : 0>;
 
 // One transform per workgroup, no loop (RTune::ONESHOT).  Forward: every thread splits exactly the
 // 16 bins its own last pass produced, so Z[k] never leaves its registers and only Z[M-k] is read
@@ -218,24 +222,28 @@ template <int LOGM> using RPlan = Plan<LOGM, (LOGM == 10 || LOGM == 11) ? (1 << 
 // loaded raw (the mirrored one at a descending scalar offset) and merged in registers.
 template <int LOGM, bool INV>
 __device__ __forceinline__ void rfft_f32_oneshot(const float2 *__restrict__ in, float2 *__restrict__ out, float2 *lds,
-                                                 const float2 *__restrict__ tw, const float2 *__restrict__ twr, uint32_t g)
+                                                 const float2 *__restrict__ tw, const float2 *__restrict__ twr, uint32_t g,
+                                                 uint32_t batch)
 {
   using PL = RPlan<LOGM>;
-  static_assert(PL::TPB == 1, "one transform per workgroup");
   constexpr int M = PL::N;
-  constexpr uint32_t BYTES = M * sizeof(float2);
+  // one descriptor over the group's valid transforms (TPB = 1 from 1024 complex points on, 4 / 2 in
+  // the single wave of 256 / 512): loads past it read zeros, stores past it are dropped
+  const uint32_t t0 = g * PL::TPB;
+  const uint32_t nvalid = batch - t0 < (uint32_t)PL::TPB ? batch - t0 : (uint32_t)PL::TPB;
+  const uint32_t BYTES = nvalid * M * (uint32_t)sizeof(float2);
   constexpr int AUX = RTune<LOGM>::AUX;
   const int tid = threadIdx.x;
   auto load2 = [](const __amdgpu_buffer_rsrc_t &rs, int voff, int soff) -> float2 {
     const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, AUX);
     return make_float2(__uint_as_float(w[0]), __uint_as_float(w[1]));
   };
-  const __amdgpu_buffer_rsrc_t ri = transform_rsrc(in + (size_t)g * M, BYTES);
-  const __amdgpu_buffer_rsrc_t ro = transform_rsrc(out + (size_t)g * M, BYTES);
+  const __amdgpu_buffer_rsrc_t ri = transform_rsrc(in + (size_t)t0 * M, BYTES);
+  const __amdgpu_buffer_rsrc_t ro = transform_rsrc(out + (size_t)t0 * M, BYTES);
   TwPow<PL, ~0u, RTune<LOGM>::NESTED8> twp;
   if constexpr (!INV) {
     float2 v[16];
-    for_each_first_pass_input_split<PL>(tid, [&](int slot, int, int j, int roff) { v[slot] = load2(ri, j * 8, roff * 8); });
+    for_each_first_pass_input_split<PL>(tid, [&](int slot, int t, int j, int roff) { v[slot] = load2(ri, ((t << LOGM) + j) * 8, roff * 8); });
     twp.preload(tw, tid);
     float2 csr[16];  // split factors (sin, cos) of the 16 bins this thread's last pass produces
     for_each_last_pass_output<PL>(tid, [&](int slot, int, int e0, int roff) { csr[slot] = twr[e0 + roff]; });
@@ -243,10 +251,10 @@ __device__ __forceinline__ void rfft_f32_oneshot(const float2 *__restrict__ in, 
     fft_block_preloaded<PL, true>(v, lds, twp, tid, st);
     __syncthreads();
     // split: bin k from Z[k] (still in v[]) and Z[M-k]
-    for_each_last_pass_output<PL>(tid, [&](int slot, int, int e0, int roff) {
+    for_each_last_pass_output<PL>(tid, [&](int slot, int t, int e0, int roff) {
       const int k = e0 + roff;
       const float2 A = v[slot];
-      const float2 B = lds[PL::idx(0, (M - k) & (M - 1))];
+      const float2 B = lds[PL::idx(t, (M - k) & (M - 1))];
       const float2 c = csr[slot];
       const float a = B.x - A.x, b = B.y + A.y;
       float2 o;
@@ -256,16 +264,15 @@ __device__ __forceinline__ void rfft_f32_oneshot(const float2 *__restrict__ in, 
       u32x2 w;
       w[0] = __float_as_uint(o.x);
       w[1] = __float_as_uint(o.y);
-      __builtin_amdgcn_raw_buffer_store_b64(w, ro, e0 * 8, roff * 8, AUX);
+      __builtin_amdgcn_raw_buffer_store_b64(w, ro, ((t << LOGM) + e0) * 8, roff * 8, AUX);
       if ((slot & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     });
   } else {
-    static_assert(PL::lr(0) == 4, "first pass of radix 16");
-    constexpr int S = M / 16;
+    constexpr int R0 = 1 << PL::lr(0), S = M / R0, TOP = (R0 - 1) * S;  // first-pass legs: j + r*S, j < S
     float2 A[16], B[16], cm[16];
-    for_each_first_pass_input_split<PL>(tid, [&](int slot, int, int j, int roff) {
-      A[slot] = load2(ri, j * 8, roff * 8);
-      B[slot] = load2(ri, (M - j - 15 * S) * 8, (15 * S - roff) * 8);   // bin M - e; e == 0 reads past the end: zero, unused
+    for_each_first_pass_input_split<PL>(tid, [&](int slot, int t, int j, int roff) {
+      A[slot] = load2(ri, ((t << LOGM) + j) * 8, roff * 8);
+      B[slot] = load2(ri, ((t << LOGM) + M - j - TOP) * 8, (TOP - roff) * 8);   // bin M - e; e == 0 reads the point after the transform: unused
     });
     for_each_first_pass_input_split<PL>(tid, [&](int slot, int, int j, int roff) { cm[slot] = twr[j + roff]; });
     twp.preload(tw, tid);
@@ -298,7 +305,7 @@ __global__ __launch_bounds__(RPlan<LOGM>::T, RTune<LOGM>::MINW) void rfft_f32_ke
   extern __shared__ __attribute__((aligned(16))) float2 lds[];
   if constexpr (RTune<LOGM>::ONESHOT) {
     const uint32_t g = blockIdx.x + blockIdx.y * gridDim.x;
-    if (g < ngroups) rfft_f32_oneshot<LOGM, INV>(in, out, lds, tw, twr, g);
+    if (g < ngroups) rfft_f32_oneshot<LOGM, INV>(in, out, lds, tw, twr, g, batch);
     return;
   }
   const int tid = threadIdx.x;

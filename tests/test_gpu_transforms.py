@@ -377,3 +377,37 @@ def test_cfft_f32_more_groups_than_one_grid_row():
     sub = x[idx].cpu().numpy().copy()
     assert H.oracle().orc_cfft_f32_batch(ptr(sub, c_f), n, len(idx), 0, 1) == 0
     assert H.rel_l2(y[idx].cpu().numpy(), sub) <= 5e-7
+
+
+@pytest.mark.parametrize("n", [256, 512, 1024, 4096])
+def test_f32_ragged_tail_writes_nothing_past_the_batch(n):
+    """Kernels that bound their accesses with a buffer descriptor over the group's valid
+    transforms (several transforms per workgroup at 256/512 points): with a batch that is not a
+    multiple of the group size, the transforms AFTER the batch in the same allocation must come
+    back untouched, for the complex transform (in place) and the real one (out of place)."""
+    import torch
+    import fft_amd
+    G = _gpu()
+    batch, extra = 7, 5
+    x = H.rng(1700 + n).uniform(-1, 1, (batch + extra, 2 * n)).astype(np.float32)
+    t = torch.from_numpy(x).cuda()
+    S = G.cfft_inst("f32", n)
+    G.check(fft_amd.lib.arm_cfft_f32_dev(ctypes.byref(S), ctypes.c_void_p(t.data_ptr()), batch, 0, 1, G.stream_ptr()))
+    torch.cuda.synchronize()
+    got = t.cpu().numpy()
+    assert np.array_equal(got[batch:], x[batch:])
+    assert np.array_equal(got[:batch], G.cfft_dev("f32", x[:batch], n, 0))
+    for ifft in (0, 1):
+        xr = x[:, :n].copy()
+        if ifft:
+            xr = G.rfft_dev(xr, n, 0)[0]
+        ti = torch.from_numpy(xr).cuda()
+        to = torch.full_like(ti, 777.0)
+        R = G.rfft_inst(n)
+        G.check(fft_amd.lib.arm_rfft_fast_f32_dev(ctypes.byref(R), ctypes.c_void_p(ti.data_ptr()), ctypes.c_void_p(to.data_ptr()), batch, ifft,
+                                                  G.stream_ptr()))
+        torch.cuda.synchronize()
+        out = to.cpu().numpy()
+        assert np.all(out[batch:] == 777.0)
+        assert np.array_equal(out[:batch], G.rfft_dev(xr[:batch], n, ifft)[0])
+        assert np.array_equal(ti.cpu().numpy(), xr)
