@@ -13,7 +13,7 @@ run() { # name, seconds, rocprof args..., -- program
   local name=$1 secs=$2; shift 2
   timeout -s KILL "$secs" rocprofv3 "$@" > "$OUT/$name.log" 2>&1 || { echo "$name failed, see $OUT/$name.log"; tail -5 "$OUT/$name.log"; return 1; }
 }
-run kt_cfft 240 --kernel-trace --stats --output-format csv -d "$OUT/kt_cfft" -- python3 bench.py --no-cpu-baseline --steps 20 --warmup 3 || exit 1
+run kt_cfft 240 --kernel-trace --stats --output-format csv -d "$OUT/kt_cfft" -- python3 bench.py --no-cpu-baseline --steps 20 --warmup 8 || exit 1
 run pmc_fetch 120 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 bench.py --no-cpu-baseline --steps 3 --warmup 1 || exit 1
 run pmc_write 120 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 bench.py --no-cpu-baseline --steps 3 --warmup 1 || exit 1
 python3 tools/summarize_prof.py "$OUT" "$OUT/cfft_f32_4096x65536.txt" cfft_f32_kernel > /dev/null
