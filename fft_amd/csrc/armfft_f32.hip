@@ -206,13 +206,17 @@ __global__ __launch_bounds__(CPlan<LOGN>::T, Tune<LOGN>::MINW) void cfft_f32_ker
 // transform per workgroup of M/16 threads from 1024 on, 4 / 2 transforms in one wave at 256 / 512
 // (512 real points 5.0 -> 5.45 TB/s, 1024: 4.5 -> 5.48); below, the plain kernel.  (Staging the
 // 32-point case through LDS like the 16-point complex kernel measured no gain: 3.7 TB/s both ways.)
-template <int LOGM> struct RTune { static constexpr int MINW = 4, AUX = 0; static constexpr bool NESTED8 = false, ONESHOT = false; };
-template <> struct RTune<8> { static constexpr int MINW = 4, AUX = 2; static constexpr bool NESTED8 = false, ONESHOT = true; };
-template <> struct RTune<9> { static constexpr int MINW = 4, AUX = 2; static constexpr bool NESTED8 = false, ONESHOT = true; };
-template <> struct RTune<10> { static constexpr int MINW = 4, AUX = 2; static constexpr bool NESTED8 = false, ONESHOT = true; };
-template <> struct RTune<11> { static constexpr int MINW = 4, AUX = 2; static constexpr bool NESTED8 = false, ONESHOT = true; };
-template <> struct RTune<12> { static constexpr int MINW = 4, AUX = 2; static constexpr bool NESTED8 = false, ONESHOT = true; };
-template <> struct RTune<13> { static constexpr int MINW = 4, AUX = 2; static constexpr bool NESTED8 = true, ONESHOT = true; };
+// SUMSPLIT: the split / merge factors of a thread's 16 bins come from ONE per-lane table load per
+// butterfly (bin e0) and angle sums with table entries at compile-time offsets (uniform address:
+// scalar loads) instead of 16 per-lane loads; same-box A/B per size, real points: 1024 +5 %,
+// 2048 +4.5 %, 4096 +3.6 %, 16384 +4 %, but 512 -3 % and 8192 -3 % (left on plain loads).
+template <int LOGM> struct RTune { static constexpr int MINW = 4, AUX = 0; static constexpr bool NESTED8 = false, ONESHOT = false, SUMSPLIT = false; };
+template <> struct RTune<8> { static constexpr int MINW = 4, AUX = 2; static constexpr bool NESTED8 = false, ONESHOT = true, SUMSPLIT = false; };
+template <> struct RTune<9> { static constexpr int MINW = 4, AUX = 2; static constexpr bool NESTED8 = false, ONESHOT = true, SUMSPLIT = true; };
+template <> struct RTune<10> { static constexpr int MINW = 4, AUX = 2; static constexpr bool NESTED8 = false, ONESHOT = true, SUMSPLIT = true; };
+template <> struct RTune<11> { static constexpr int MINW = 4, AUX = 2; static constexpr bool NESTED8 = false, ONESHOT = true, SUMSPLIT = true; };
+template <> struct RTune<12> { static constexpr int MINW = 4, AUX = 2; static constexpr bool NESTED8 = false, ONESHOT = true, SUMSPLIT = false; };
+template <> struct RTune<13> { static constexpr int MINW = 4, AUX = 2; static constexpr bool NESTED8 = true, ONESHOT = true, SUMSPLIT = true; };
 
 template <int LOGM> using RPlan = Plan<LOGM, (LOGM == 8 || LOGM == 9) ? 64 : (LOGM == 10 || LOGM == 11) ? (1 << LOGM) / 16 : 0>;
 
@@ -246,7 +250,19 @@ __device__ __forceinline__ void rfft_f32_oneshot(const float2 *__restrict__ in, 
     for_each_first_pass_input_split<PL>(tid, [&](int slot, int t, int j, int roff) { v[slot] = load2(ri, ((t << LOGM) + j) * 8, roff * 8); });
     twp.preload(tw, tid);
     float2 csr[16];  // split factors (sin, cos) of the 16 bins this thread's last pass produces
-    for_each_last_pass_output<PL>(tid, [&](int slot, int, int e0, int roff) { csr[slot] = twr[e0 + roff]; });
+    // SUMSPLIT: ONE per-lane load (bin e0) per butterfly; the factor of bin e0 + roff is its angle
+    // sum with the table entry `roff`, whose address is uniform -- a scalar load, not one more
+    // vector-memory instruction in front of the stores
+    float2 base;
+    for_each_last_pass_output<PL>(tid, [&](int slot, int, int e0, int roff) {
+      if (roff == 0 || !RTune<LOGM>::SUMSPLIT) {
+        base = twr[e0 + roff];
+        csr[slot] = base;
+      } else {
+        const float2 c = twr[roff];
+        csr[slot] = make_float2(base.x * c.y + base.y * c.x, base.y * c.y - base.x * c.x);  // (sin, cos)(a + b)
+      }
+    });
     auto st = [&](int t, int e, float2 x) { lds[PL::idx(t, e)] = x; };
     fft_block_preloaded<PL, true>(v, lds, twp, tid, st);
     __syncthreads();
@@ -274,7 +290,16 @@ __device__ __forceinline__ void rfft_f32_oneshot(const float2 *__restrict__ in, 
       A[slot] = load2(ri, ((t << LOGM) + j) * 8, roff * 8);
       B[slot] = load2(ri, ((t << LOGM) + M - j - TOP) * 8, (TOP - roff) * 8);   // bin M - e; e == 0 reads the point after the transform: unused
     });
-    for_each_first_pass_input_split<PL>(tid, [&](int slot, int, int j, int roff) { cm[slot] = twr[j + roff]; });
+    float2 base;
+    for_each_first_pass_input_split<PL>(tid, [&](int slot, int, int j, int roff) {
+      if (roff == 0 || !RTune<LOGM>::SUMSPLIT) {
+        base = twr[j + roff];
+        cm[slot] = base;
+      } else {
+        const float2 c = twr[roff];  // uniform address: scalar load
+        cm[slot] = make_float2(base.x * c.y + base.y * c.x, base.y * c.y - base.x * c.x);
+      }
+    });
     twp.preload(tw, tid);
     float2 v[16];
     for_each_first_pass_input_split<PL>(tid, [&](int slot, int, int j, int roff) {
