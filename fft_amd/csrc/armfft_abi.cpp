@@ -60,6 +60,12 @@ struct HostTables {
 };
 static HostTables g_host[kMaxLog + 2];
 
+static int tw_rounding()
+{
+  std::lock_guard<std::mutex> lk(g_mu);
+  return g_tw_rounding;
+}
+
 static int ilog2u(uint32_t n)
 {
   int l = 0;
@@ -370,7 +376,7 @@ static const float2 *dev_tw_lo(int logn)
 // the device could move a floor() across an integer (about 1e-7 per q31 entry), and bit-exact
 // output needs bit-exact twiddles.  On any mismatch the host table is uploaded instead.
 template <typename T>
-static T *dev_tw_fixed(T *&slot, int logn, const T *host, hipError_t (*gen)(T *, uint32_t, int, hipStream_t))
+static T *dev_tw_fixed(T *&slot, int logn, const T *host, hipError_t (*gen)(T *, uint32_t, int, hipStream_t), int rounding)
 {
   if (slot) return slot;
   uint32_t N = 1u << logn;
@@ -378,7 +384,7 @@ static T *dev_tw_fixed(T *&slot, int logn, const T *host, hipError_t (*gen)(T *,
   T *p = nullptr;
   if (!hip_ok(hipMalloc((void **)&p, bytes), "hipMalloc(fixed twiddle)")) return nullptr;
   std::vector<T> back(count);
-  bool ok = hip_ok(gen(p, N, g_tw_rounding, nullptr), "fixed twiddle generation") &&
+  bool ok = hip_ok(gen(p, N, rounding, nullptr), "fixed twiddle generation") &&
             hip_ok(hipMemcpy(back.data(), p, bytes, hipMemcpyDeviceToHost), "hipMemcpy(D2H twiddle)");
   if (ok && memcmp(back.data(), host, bytes) != 0) ok = hip_ok(hipMemcpy(p, host, bytes, hipMemcpyHostToDevice), "hipMemcpy(H2D twiddle)");
   if (!ok) {
@@ -394,8 +400,9 @@ static const int16_t *dev_tw_q15(int logn)
   int dev;
   if (!current_device(&dev)) return nullptr;
   const int16_t *host = host_tw_q15(logn);
+  const int rounding = tw_rounding();
   std::lock_guard<std::mutex> lk(g_dev_mu);
-  return dev_tw_fixed<int16_t>(g_dev[dev].tw_q15[logn], logn, host, launch_gen_twiddle_q15);
+  return dev_tw_fixed<int16_t>(g_dev[dev].tw_q15[logn], logn, host, launch_gen_twiddle_q15, rounding);
 }
 
 static const int32_t *dev_tw_q31(int logn)
@@ -403,8 +410,9 @@ static const int32_t *dev_tw_q31(int logn)
   int dev;
   if (!current_device(&dev)) return nullptr;
   const int32_t *host = host_tw_q31(logn);
+  const int rounding = tw_rounding();
   std::lock_guard<std::mutex> lk(g_dev_mu);
-  return dev_tw_fixed<int32_t>(g_dev[dev].tw_q31[logn], logn, host, launch_gen_twiddle_q31);
+  return dev_tw_fixed<int32_t>(g_dev[dev].tw_q31[logn], logn, host, launch_gen_twiddle_q31, rounding);
 }
 
 // device copies of realCoefA/B (A first, then B)

@@ -6,6 +6,8 @@
 // :316-462) with an LDS-resident Stockham transform (fft_core_f32.hpp): each transform is read
 // from HBM once and written once (16 bytes per point), twiddles come from a device-generated,
 // L2-resident table and never from HBM in steady state.
+#include <atomic>
+
 #include "armfft_internal.h"
 #include "fft_core_f32.hpp"
 
@@ -442,7 +444,7 @@ template <int LOGN, bool INV>
 static hipError_t launch_cfft_one(float2 *data, const float2 *tw, uint32_t batch, int order, hipStream_t stream)
 {
   using PL = CPlan<LOGN>;
-  static bool attr_done[16] = {false};
+  static std::atomic<bool> attr_done[16];  // zero-initialised; a racing second hipFuncSetAttribute is harmless
   int dev = 0;
   (void)hipGetDevice(&dev);
   auto kern = cfft_f32_kernel<LOGN, INV>;
@@ -475,7 +477,7 @@ static hipError_t launch_rfft_one(const float2 *in, float2 *out, const float2 *t
                                   hipStream_t stream)
 {
   using PL = RPlan<LOGM>;
-  static bool attr_done[16] = {false};
+  static std::atomic<bool> attr_done[16];  // zero-initialised; a racing second hipFuncSetAttribute is harmless
   int dev = 0;
   (void)hipGetDevice(&dev);
   auto kern = rfft_f32_kernel<LOGM, INV>;

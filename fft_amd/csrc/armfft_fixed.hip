@@ -11,6 +11,8 @@
 // LDS, two radix-4 stages are fused in registers per LDS round trip, and the bit reversal of
 // arm_bitreversal_16/_32 (arm_bitreversal2.c:84-148, plain bit reversal for the fixed tables) is
 // folded into the final, coalesced store.
+#include <atomic>
+
 #include "armfft_internal.h"
 
 namespace armfft {
@@ -510,7 +512,7 @@ static hipError_t launch_fixed_one(typename Q::word *data, const typename Q::two
   using PL = FixedPlan<LOGN>;
   constexpr int WGPCU = FixedTune<Q, LOGN>::WGPCU;
   constexpr size_t lds_bytes = (size_t)PL::LDS_WORDS * sizeof(typename Q::word) + (WGPCU ? (size_t)(3 * PL::N / 4) * sizeof(typename Q::tword) : 0);
-  static bool attr_done[16] = {false};
+  static std::atomic<bool> attr_done[16];  // zero-initialised; a racing second hipFuncSetAttribute is harmless
   int dev = 0;
   (void)hipGetDevice(&dev);
   auto kern = cfft_fixed_kernel<Q, LOGN, INV>;
@@ -746,7 +748,7 @@ static hipError_t launch_rfft_fixed_one(const typename Q::word *in, typename Q::
 {
   using PL = FixedPlan<LOGN>;
   constexpr size_t lds_bytes = (size_t)PL::LDS_WORDS * sizeof(typename Q::word);
-  static bool attr_done[16] = {false};
+  static std::atomic<bool> attr_done[16];  // zero-initialised; a racing second hipFuncSetAttribute is harmless
   int dev = 0;
   (void)hipGetDevice(&dev);
   auto kern = rfft_fixed_kernel<Q, LOGN, INV>;

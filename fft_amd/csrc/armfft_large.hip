@@ -16,6 +16,8 @@
 // Every point crosses HBM twice in each direction: 32*N bytes against the compulsory 16*N, so
 // the ceiling under SURVEY 8(d)'s accounting is 50 % of the HBM roofline; both are reported.
 // One workgroup = 1024 threads x 16 points = C sequences (C = 16384/N1), LDS 145 KiB.
+#include <atomic>
+
 #include "armfft_internal.h"
 #include "fft_core_f32.hpp"
 
@@ -222,7 +224,7 @@ static hipError_t launch_pass(const float2 *in, float2 *out, const float2 *tw, c
 {
   using PL = Plan<LOGA, 1024>;
   const size_t lds_bytes = PL::LDS_BYTES + (MODE == 1 ? sizeof(float2) * kBigEntries : 0);
-  static bool attr_done[16] = {false};
+  static std::atomic<bool> attr_done[16];  // zero-initialised; a racing second hipFuncSetAttribute is harmless
   int dev = 0;
   (void)hipGetDevice(&dev);
   auto kern = fourstep_pass_kernel<LOGA, MODE, INV, TILED>;
