@@ -43,11 +43,12 @@ __device__ __forceinline__ int scrambled_pos(int k)
 //   AUX       cache policy of the HBM accesses: 2 = nt (streamed once) where it measured faster
 // 256 and 512 points run the one-shot path in ONE wave (64 threads, 4 / 2 transforms): every wave
 // instruction then touches whole 128-byte lines (256) or one 512-byte run (512), so nt applies:
-// 5.4 -> 5.8 TB/s and 5.3 -> 5.9 TB/s.  64 and 128 points stay on the plain kernel (256 threads,
-// several transforms per workgroup, table twiddles; 5.25 / 5.5 TB/s): there a wave instruction
-// covers 32/64-byte segments, nt costs 15%, the one-shot form without nt and LDS staging measured
-// the same or slower.  16 and 32 points are staged through LDS with 16-byte accesses (nt pays at
-// 16 points only: 5.48 -> 5.67 TB/s).
+// 5.4 -> 5.8 TB/s and 5.3 -> 5.9 TB/s.  128 points stay on the plain kernel (256 threads, 32
+// transforms per workgroup, table twiddles; 5.5 TB/s): there a wave instruction covers 64-byte
+// segments, nt costs 15%, the one-shot form without nt and LDS staging measured the same or
+// slower.  16, 32 and 64 points are staged through LDS with 16-byte accesses (64 points in
+// single-wave workgroups of 16 transforms: 5.25 -> 5.45 TB/s; nt pays at 16 points only: 5.48 ->
+// 5.67 TB/s).
 struct TuneBase {
   static constexpr unsigned LAZYMASK = 0;
   static constexpr int MINW = 4, AUX = 0;
@@ -68,8 +69,9 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // Plan of the complex kernel: one-shot sizes below 4096 points use N/16 threads (at least one
-// wave: 256 and 512 points put 4 / 2 transforms in it) instead of the default 256 threads.
-template <int LOGN> using CPlan = Plan<LOGN, (Tune<LOGN>::ONESHOT && LOGN < 12) ? ((1 << LOGN) / 16 < 64 ? 64 : (1 << LOGN) / 16) : 0>;
+// wave: 256 and 512 points put 4 / 2 transforms in it) instead of the default 256 threads; the staged
+// 64-point kernel uses single-wave workgroups too.
+template <int LOGN> using CPlan = Plan<LOGN, LOGN == 6 ? 64 : (Tune<LOGN>::ONESHOT && LOGN < 12) ? ((1 << LOGN) / 16 < 64 ? 64 : (1 << LOGN) / 16) : 0>;
 
 // Buffer descriptor over one transform (gfx9 raw buffer: stride 0, range in bytes, 32-bit data
 // format): address = base + scalar offset + per-lane offset, so the 16 legs of a thread share ONE
@@ -145,8 +147,8 @@ __global__ __launch_bounds__(CPlan<LOGN>::T, Tune<LOGN>::MINW) void cfft_f32_ker
     }
     return;
   }
-  if constexpr (LOGN <= 5) {
-    // 16 and 32 points: a thread's first-pass legs are 8 bytes at a 128/256-byte stride across
+  if constexpr (LOGN <= 6) {
+    // 16 and 32 points (and 64, in single-wave workgroups): a thread's first-pass legs are 8 bytes at a 128/256-byte stride across
     // lanes, so the workgroup's transforms (one contiguous 32 KiB block) are staged through LDS
     // with 16-byte coalesced accesses instead, in and out
     const uint32_t g = g0;
