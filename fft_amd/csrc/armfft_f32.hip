@@ -41,14 +41,15 @@ __device__ __forceinline__ int scrambled_pos(int k)
 //             next transform (which need 170-230 VGPRs): 4096 0.85 -> 0.78 ms per 65536.
 //   MINW      __launch_bounds__ waves per SIMD (register budget 512 / MINW)
 //   AUX       cache policy of the HBM accesses: 2 = nt (streamed once) where it measured faster
-// 256 and 512 points run the one-shot path in ONE wave (64 threads, 4 / 2 transforms): every wave
+// Single-wave workgroups (64 threads) everywhere below 2048 points: a wave that never waits for
+// another wave at a barrier streams best (same-box A/B: 16 points 5.65 -> 6.03 TB/s, 32: 5.23 ->
+// 5.55, 64: 5.25 -> 5.45, 128: 5.49 -> 5.62).
+// 256 and 512 points run the one-shot path that way (4 / 2 transforms per wave): every wave
 // instruction then touches whole 128-byte lines (256) or one 512-byte run (512), so nt applies:
-// 5.4 -> 5.8 TB/s and 5.3 -> 5.9 TB/s.  128 points stay on the plain kernel (256 threads, 32
-// transforms per workgroup, table twiddles; 5.5 TB/s): there a wave instruction covers 64-byte
-// segments, nt costs 15%, the one-shot form without nt and LDS staging measured the same or
-// slower.  16, 32 and 64 points are staged through LDS with 16-byte accesses (64 points in
-// single-wave workgroups of 16 transforms: 5.25 -> 5.45 TB/s; nt pays at 16 points only: 5.48 ->
-// 5.67 TB/s).
+// 5.4 -> 5.8 TB/s and 5.3 -> 5.9 TB/s.  128 points stay on the plain kernel (8 transforms per
+// wave, table twiddles): there a wave instruction covers 64-byte segments, nt costs 15%, the
+// one-shot form without nt and LDS staging measured the same or slower.  16, 32 and 64 points are
+// staged through LDS with 16-byte accesses (nt pays at 16 points only).
 struct TuneBase {
   static constexpr unsigned LAZYMASK = 0;
   static constexpr int MINW = 4, AUX = 0;
@@ -69,9 +70,9 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // Plan of the complex kernel: one-shot sizes below 4096 points use N/16 threads (at least one
-// wave: 256 and 512 points put 4 / 2 transforms in it) instead of the default 256 threads; the staged
-// 64-point kernel uses single-wave workgroups too.
-template <int LOGN> using CPlan = Plan<LOGN, LOGN == 6 ? 64 : (Tune<LOGN>::ONESHOT && LOGN < 12) ? ((1 << LOGN) / 16 < 64 ? 64 : (1 << LOGN) / 16) : 0>;
+// wave: 256 and 512 points put 4 / 2 transforms in it); the staged and plain kernels below 256
+// points use single-wave workgroups too.
+template <int LOGN> using CPlan = Plan<LOGN, LOGN <= 7 ? 64 : (Tune<LOGN>::ONESHOT && LOGN < 12) ? ((1 << LOGN) / 16 < 64 ? 64 : (1 << LOGN) / 16) : 0>;
 
 // Buffer descriptor over one transform (gfx9 raw buffer: stride 0, range in bytes, 32-bit data
 // format): address = base + scalar offset + per-lane offset, so the 16 legs of a thread share ONE
@@ -222,7 +223,8 @@ template <> struct RTune<11> { static constexpr int MINW = 4, AUX = 2; static co
 template <> struct RTune<12> { static constexpr int MINW = 4, AUX = 2; static constexpr bool NESTED8 = false, ONESHOT = true, SUMSPLIT = false; };
 template <> struct RTune<13> { static constexpr int MINW = 4, AUX = 2; static constexpr bool NESTED8 = true, ONESHOT = true, SUMSPLIT = true; };
 
-template <int LOGM> using RPlan = Plan<LOGM, (LOGM == 8 || LOGM == 9) ? 64 : (LOGM == 10 || LOGM == 11) ? (1 << LOGM) / 16 : 0>;
+// (64 and 128 real points in single-wave workgroups as well: +3.5 % / +6 %)
+template <int LOGM> using RPlan = Plan<LOGM, (LOGM == 5 || LOGM == 6 || LOGM == 8 || LOGM == 9) ? 64 : (LOGM == 10 || LOGM == 11) ? (1 << LOGM) / 16 : 0>;
 
 // One transform per workgroup, no loop (RTune::ONESHOT).  Forward: every thread splits exactly the
 // 16 bins its own last pass produced, so Z[k] never leaves its registers and only Z[M-k] is read
