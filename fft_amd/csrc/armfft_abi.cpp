@@ -294,8 +294,10 @@ struct DevPlans {
   int16_t *tw_q15[kMaxLog + 2] = {};
   int32_t *tw_q31[kMaxLog + 2] = {};
   float2 *tw_lo[kMaxLargeLog + 1] = {};
-  int16_t *rc15 = nullptr;  // realCoefA | realCoefB, 2 x 8192 q15
-  int32_t *rc31 = nullptr;
+  // realCoefA | realCoefB as the n_real-point transform reads them: entries i * twidCoefRModifier,
+  // i < n_real/2, compacted per size so that consecutive lanes read consecutive entries
+  int16_t *rc15[14] = {};
+  int32_t *rc31[14] = {};
   void *stage = nullptr;  // grow-only staging buffers for the host-pointer entry points
   size_t stage_bytes = 0;
   void *stage2 = nullptr;
@@ -415,16 +417,23 @@ static const int32_t *dev_tw_q31(int logn)
   return dev_tw_fixed<int32_t>(g_dev[dev].tw_q31[logn], logn, host, launch_gen_twiddle_q31, rounding);
 }
 
-// device copies of realCoefA/B (A first, then B)
+// device copies of realCoefA/B for n_real = 2^l: L = n_real/2 pairs of A (entries i * mod of the 4096-pair
+// table, mod = 8192 / n_real = twidCoefRModifier), then L pairs of B
 template <typename T>
-static const T *dev_real_coef(T *&slot, const std::vector<T> &A, const std::vector<T> &B)
+static const T *dev_real_coef(T *&slot, const std::vector<T> &A, const std::vector<T> &B, int l)
 {
   if (!slot) {
+    const size_t L = (size_t)1 << (l - 1), mod = (size_t)8192 >> l;
+    std::vector<T> h(4 * L);
+    for (size_t i = 0; i < L; i++) {
+      h[2 * i] = A[2 * i * mod];
+      h[2 * i + 1] = A[2 * i * mod + 1];
+      h[2 * L + 2 * i] = B[2 * i * mod];
+      h[2 * L + 2 * i + 1] = B[2 * i * mod + 1];
+    }
     T *p = nullptr;
-    const size_t n = A.size();
-    if (!hip_ok(hipMalloc((void **)&p, sizeof(T) * 2 * n), "hipMalloc(realCoef)")) return nullptr;
-    if (!hip_ok(hipMemcpy(p, A.data(), sizeof(T) * n, hipMemcpyHostToDevice), "hipMemcpy(realCoefA)") ||
-        !hip_ok(hipMemcpy(p + n, B.data(), sizeof(T) * n, hipMemcpyHostToDevice), "hipMemcpy(realCoefB)")) {
+    if (!hip_ok(hipMalloc((void **)&p, sizeof(T) * h.size()), "hipMalloc(realCoef)")) return nullptr;
+    if (!hip_ok(hipMemcpy(p, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice), "hipMemcpy(realCoef)")) {
       (void)hipFree(p);
       return nullptr;
     }
@@ -432,21 +441,21 @@ static const T *dev_real_coef(T *&slot, const std::vector<T> &A, const std::vect
   }
   return slot;
 }
-static const int16_t *dev_rc15()
+static const int16_t *dev_rc15(int l)
 {
   int dev;
   if (!current_device(&dev)) return nullptr;
   const RealCoef &rc = host_real_coef();
   std::lock_guard<std::mutex> lk(g_dev_mu);
-  return dev_real_coef<int16_t>(g_dev[dev].rc15, rc.a15, rc.b15);
+  return dev_real_coef<int16_t>(g_dev[dev].rc15[l], rc.a15, rc.b15, l);
 }
-static const int32_t *dev_rc31()
+static const int32_t *dev_rc31(int l)
 {
   int dev;
   if (!current_device(&dev)) return nullptr;
   const RealCoef &rc = host_real_coef();
   std::lock_guard<std::mutex> lk(g_dev_mu);
-  return dev_real_coef<int32_t>(g_dev[dev].rc31, rc.a31, rc.b31);
+  return dev_real_coef<int32_t>(g_dev[dev].rc31[l], rc.a31, rc.b31, l);
 }
 
 // n_real = 32 .. 8192 (arm_rfft_init_q15.c:178-370; the fork's 16384 entry reuses modifier 1 on the
@@ -706,9 +715,9 @@ arm_status arm_rfft_q15_dev(const arm_rfft_instance_q15 *S, const q15_t *pSrc, q
   if (!S || !pSrc || !pDst) { set_error("arm_rfft_q15_dev: null argument"); return ARM_MATH_ARGUMENT_ERROR; }
   const int l = rfft_fixed_log(S->fftLenReal);
   if (l < 0) { set_error("arm_rfft_q15_dev: unsupported fftLenReal %u", S->fftLenReal); return ARM_MATH_ARGUMENT_ERROR; }
-  const int16_t *tw = dev_tw_q15(l - 1), *rc = dev_rc15();
+  const int16_t *tw = dev_tw_q15(l - 1), *rc = dev_rc15(l);
   if (!tw || !rc) return ARM_MATH_ARGUMENT_ERROR;
-  hipError_t e = launch_rfft_q15(l, pSrc, pDst, tw, rc, rc + 2 * kRealCoefPairs, (int)(8192u >> l), batch, S->ifftFlagR != 0,
+  hipError_t e = launch_rfft_q15(l, pSrc, pDst, tw, rc, rc + ((size_t)1 << l), 1, batch, S->ifftFlagR != 0,
                                  S->bitReverseFlagR != 0, (hipStream_t)stream);
   return hip_ok(e, "rfft_q15 launch") ? ARM_MATH_SUCCESS : ARM_MATH_ARGUMENT_ERROR;
 }
@@ -717,9 +726,9 @@ arm_status arm_rfft_q31_dev(const arm_rfft_instance_q31 *S, const q31_t *pSrc, q
   if (!S || !pSrc || !pDst) { set_error("arm_rfft_q31_dev: null argument"); return ARM_MATH_ARGUMENT_ERROR; }
   const int l = rfft_fixed_log(S->fftLenReal);
   if (l < 0) { set_error("arm_rfft_q31_dev: unsupported fftLenReal %u", S->fftLenReal); return ARM_MATH_ARGUMENT_ERROR; }
-  const int32_t *tw = dev_tw_q31(l - 1), *rc = dev_rc31();
+  const int32_t *tw = dev_tw_q31(l - 1), *rc = dev_rc31(l);
   if (!tw || !rc) return ARM_MATH_ARGUMENT_ERROR;
-  hipError_t e = launch_rfft_q31(l, pSrc, pDst, tw, rc, rc + 2 * kRealCoefPairs, (int)(8192u >> l), batch, S->ifftFlagR != 0,
+  hipError_t e = launch_rfft_q31(l, pSrc, pDst, tw, rc, rc + ((size_t)1 << l), 1, batch, S->ifftFlagR != 0,
                                  S->bitReverseFlagR != 0, (hipStream_t)stream);
   return hip_ok(e, "rfft_q31 launch") ? ARM_MATH_SUCCESS : ARM_MATH_ARGUMENT_ERROR;
 }
