@@ -301,7 +301,7 @@ def test_cfft_fixed_full_batch_checksum():
         assert torch.equal(t.view(batch // sub, sub, 2 * n), w.unsqueeze(0).expand(batch // sub, sub, 2 * n))
 
 
-# ---------------------------------------------------------------- persistent kernels: several rounds per workgroup
+# ---------------------------------------------------------------- large batches: more workgroups than fit the chip at once
 def _chunked(fn, x, chunk=64):
     """The same transforms, at most `chunk` per launch: every workgroup runs a single round."""
     return np.concatenate([fn(x[i:i + chunk]) for i in range(0, len(x), chunk)], axis=0)
@@ -347,7 +347,8 @@ def test_rfft_f32_many_rounds_equal_single_round(n, ifft):
 
 @pytest.mark.parametrize("ifft", [0, 1])
 def test_cfft_q15_4096_many_rounds_bit_exact(ifft):
-    """The persistent q15 kernel (5 workgroups per CU): three rounds and a tail, against the oracle."""
+    """A q15 batch of several thousand 4096-point transforms with a ragged tail, against the oracle
+    (written for the earlier persistent kernel; kept as the large-batch bit-exactness check)."""
     G = _gpu()
     n, batch = 4096, 2 * 1280 + 37
     x = H.rng(1600 + ifft).integers(-16384, 16384, (batch, 2 * n)).astype(np.int16)
