@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -306,10 +307,33 @@ struct DevPlans {
 static DevPlans g_dev[kMaxDev];
 static std::mutex g_dev_mu;
 
+// Plan slots are written once (under g_dev_mu, with a release store once the table is complete) and
+// never freed, so steady-state launches read them with one acquire load and take no lock.
+template <typename T>
+static inline T *slot_peek(T *const &slot) { return __atomic_load_n(&slot, __ATOMIC_ACQUIRE); }
+template <typename T>
+static inline void slot_publish(T *&slot, T *p) { __atomic_store_n(&slot, p, __ATOMIC_RELEASE); }
+
+// _dev entry points: the kernels use 16-byte vector accesses on the data (armfft_f32.hip staged path,
+// armfft_fixed.hip loads/stores), so device pointers must be 16-byte aligned (hipMalloc gives 256)
+static bool aligned16(const void *p, const char *fn)
+{
+  if (((uintptr_t)p & 15u) == 0) return true;
+  set_error("%s: device pointer %p is not 16-byte aligned", fn, p);
+  return false;
+}
+
 static bool current_device(int *dev)
 {
-  int n = 0;
-  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+  // the device count cannot change during the life of the process: ask once (a launch otherwise pays
+  // for it every time, ~3 us)
+  static std::atomic<int> n_cached{-1};
+  int n = n_cached.load(std::memory_order_relaxed);
+  if (n < 0) {
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) n = 0;
+    n_cached.store(n, std::memory_order_relaxed);
+  }
+  if (n <= 0) {
     set_error("no HIP device available: libarmfft_mi355 has no CPU path");
     return false;
   }
@@ -325,16 +349,18 @@ static const float2 *dev_tw_f32(int logn)
 {
   int dev;
   if (!current_device(&dev)) return nullptr;
+  float2 *&slot = g_dev[dev].tw_f32[logn];
+  if (float2 *q = slot_peek(slot)) return q;
   std::lock_guard<std::mutex> lk(g_dev_mu);
-  float2 *&p = g_dev[dev].tw_f32[logn];
-  if (!p) {
-    uint32_t N = 1u << logn;
-    if (!hip_ok(hipMalloc((void **)&p, sizeof(float2) * N), "hipMalloc(twiddle)")) { p = nullptr; return nullptr; }
-    if (!hip_ok(launch_gen_twiddle_f32(p, N, nullptr), "twiddle generation") || !hip_ok(hipStreamSynchronize(nullptr), "sync")) {
-      (void)hipFree(p);
-      p = nullptr;
-    }
+  if (slot) return slot;
+  float2 *p = nullptr;
+  uint32_t N = 1u << logn;
+  if (!hip_ok(hipMalloc((void **)&p, sizeof(float2) * N), "hipMalloc(twiddle)")) return nullptr;
+  if (!hip_ok(launch_gen_twiddle_f32(p, N, nullptr), "twiddle generation") || !hip_ok(hipStreamSynchronize(nullptr), "sync")) {
+    (void)hipFree(p);
+    return nullptr;
   }
+  slot_publish(slot, p);
   return p;
 }
 
@@ -342,16 +368,18 @@ static const float2 *dev_tw_rfft(int logn_real)
 {
   int dev;
   if (!current_device(&dev)) return nullptr;
+  float2 *&slot = g_dev[dev].tw_rfft[logn_real];
+  if (float2 *q = slot_peek(slot)) return q;
   std::lock_guard<std::mutex> lk(g_dev_mu);
-  float2 *&p = g_dev[dev].tw_rfft[logn_real];
-  if (!p) {
-    uint32_t N = 1u << logn_real;
-    if (!hip_ok(hipMalloc((void **)&p, sizeof(float2) * (N / 2)), "hipMalloc(rfft twiddle)")) { p = nullptr; return nullptr; }
-    if (!hip_ok(launch_gen_twiddle_rfft(p, N, nullptr), "rfft twiddle generation") || !hip_ok(hipStreamSynchronize(nullptr), "sync")) {
-      (void)hipFree(p);
-      p = nullptr;
-    }
+  if (slot) return slot;
+  float2 *p = nullptr;
+  uint32_t N = 1u << logn_real;
+  if (!hip_ok(hipMalloc((void **)&p, sizeof(float2) * (N / 2)), "hipMalloc(rfft twiddle)")) return nullptr;
+  if (!hip_ok(launch_gen_twiddle_rfft(p, N, nullptr), "rfft twiddle generation") || !hip_ok(hipStreamSynchronize(nullptr), "sync")) {
+    (void)hipFree(p);
+    return nullptr;
   }
+  slot_publish(slot, p);
   return p;
 }
 
@@ -361,15 +389,17 @@ static const float2 *dev_tw_lo(int logn)
 {
   int dev;
   if (!current_device(&dev)) return nullptr;
+  float2 *&slot = g_dev[dev].tw_lo[logn];
+  if (float2 *q = slot_peek(slot)) return q;
   std::lock_guard<std::mutex> lk(g_dev_mu);
-  float2 *&p = g_dev[dev].tw_lo[logn];
-  if (!p) {
-    if (!hip_ok(hipMalloc((void **)&p, sizeof(float2) * 1024), "hipMalloc(lo twiddle)")) { p = nullptr; return nullptr; }
-    if (!hip_ok(launch_gen_twiddle_lo(p, logn, nullptr), "lo twiddle generation") || !hip_ok(hipStreamSynchronize(nullptr), "sync")) {
-      (void)hipFree(p);
-      p = nullptr;
-    }
+  if (slot) return slot;
+  float2 *p = nullptr;
+  if (!hip_ok(hipMalloc((void **)&p, sizeof(float2) * 1024), "hipMalloc(lo twiddle)")) return nullptr;
+  if (!hip_ok(launch_gen_twiddle_lo(p, logn, nullptr), "lo twiddle generation") || !hip_ok(hipStreamSynchronize(nullptr), "sync")) {
+    (void)hipFree(p);
+    return nullptr;
   }
+  slot_publish(slot, p);
   return p;
 }
 
@@ -393,14 +423,15 @@ static T *dev_tw_fixed(T *&slot, int logn, const T *host, hipError_t (*gen)(T *,
     (void)hipFree(p);
     return nullptr;
   }
-  slot = p;
-  return slot;
+  slot_publish(slot, p);
+  return p;
 }
 
 static const int16_t *dev_tw_q15(int logn)
 {
   int dev;
   if (!current_device(&dev)) return nullptr;
+  if (int16_t *q = slot_peek(g_dev[dev].tw_q15[logn])) return q;
   const int16_t *host = host_tw_q15(logn);
   const int rounding = tw_rounding();
   std::lock_guard<std::mutex> lk(g_dev_mu);
@@ -411,6 +442,7 @@ static const int32_t *dev_tw_q31(int logn)
 {
   int dev;
   if (!current_device(&dev)) return nullptr;
+  if (int32_t *q = slot_peek(g_dev[dev].tw_q31[logn])) return q;
   const int32_t *host = host_tw_q31(logn);
   const int rounding = tw_rounding();
   std::lock_guard<std::mutex> lk(g_dev_mu);
@@ -437,7 +469,7 @@ static const T *dev_real_coef(T *&slot, const std::vector<T> &A, const std::vect
       (void)hipFree(p);
       return nullptr;
     }
-    slot = p;
+    slot_publish(slot, p);
   }
   return slot;
 }
@@ -445,6 +477,7 @@ static const int16_t *dev_rc15(int l)
 {
   int dev;
   if (!current_device(&dev)) return nullptr;
+  if (int16_t *q = slot_peek(g_dev[dev].rc15[l])) return q;
   const RealCoef &rc = host_real_coef();
   std::lock_guard<std::mutex> lk(g_dev_mu);
   return dev_real_coef<int16_t>(g_dev[dev].rc15[l], rc.a15, rc.b15, l);
@@ -453,6 +486,7 @@ static const int32_t *dev_rc31(int l)
 {
   int dev;
   if (!current_device(&dev)) return nullptr;
+  if (int32_t *q = slot_peek(g_dev[dev].rc31[l])) return q;
   const RealCoef &rc = host_real_coef();
   std::lock_guard<std::mutex> lk(g_dev_mu);
   return dev_real_coef<int32_t>(g_dev[dev].rc31[l], rc.a31, rc.b31, l);
@@ -580,6 +614,7 @@ arm_status arm_cfft_f32_dev(const arm_cfft_instance_f32 *S, float32_t *p, uint32
                             void *stream)
 {
   if (!S || !p) { set_error("arm_cfft_f32_dev: null argument"); return ARM_MATH_ARGUMENT_ERROR; }
+  if (!aligned16(p, "arm_cfft_f32_dev")) return ARM_MATH_ARGUMENT_ERROR;
   int l = cfft_log(S->fftLen);
   if (l < 0) { set_error("arm_cfft_f32_dev: unsupported fftLen %u", (unsigned)S->fftLen); return ARM_MATH_ARGUMENT_ERROR; }
   const float2 *tw = dev_tw_f32(l);
@@ -626,6 +661,7 @@ arm_status arm_cfft_radix2_init_f32(arm_cfft_radix2_instance_f32 *S, uint16_t ff
 arm_status arm_cfft_radix2_f32_dev(const arm_cfft_radix2_instance_f32 *S, float32_t *p, uint32_t batch, void *stream)
 {
   if (!S || !p) { set_error("arm_cfft_radix2_f32_dev: null argument"); return ARM_MATH_ARGUMENT_ERROR; }
+  if (!aligned16(p, "arm_cfft_radix2_f32_dev")) return ARM_MATH_ARGUMENT_ERROR;
   int l = cfft_log(S->fftLen);
   if (l < 0) { set_error("arm_cfft_radix2_f32_dev: unsupported fftLen %u", (unsigned)S->fftLen); return ARM_MATH_ARGUMENT_ERROR; }
   const float2 *tw = dev_tw_f32(l);
@@ -713,6 +749,7 @@ ARMFFT_RFIX_INIT_N(1024) ARMFFT_RFIX_INIT_N(2048) ARMFFT_RFIX_INIT_N(4096) ARMFF
 arm_status arm_rfft_q15_dev(const arm_rfft_instance_q15 *S, const q15_t *pSrc, q15_t *pDst, uint32_t batch, void *stream)
 {
   if (!S || !pSrc || !pDst) { set_error("arm_rfft_q15_dev: null argument"); return ARM_MATH_ARGUMENT_ERROR; }
+  if (!aligned16(pSrc, "arm_rfft_q15_dev") || !aligned16(pDst, "arm_rfft_q15_dev")) return ARM_MATH_ARGUMENT_ERROR;
   const int l = rfft_fixed_log(S->fftLenReal);
   if (l < 0) { set_error("arm_rfft_q15_dev: unsupported fftLenReal %u", S->fftLenReal); return ARM_MATH_ARGUMENT_ERROR; }
   const int16_t *tw = dev_tw_q15(l - 1), *rc = dev_rc15(l);
@@ -724,6 +761,7 @@ arm_status arm_rfft_q15_dev(const arm_rfft_instance_q15 *S, const q15_t *pSrc, q
 arm_status arm_rfft_q31_dev(const arm_rfft_instance_q31 *S, const q31_t *pSrc, q31_t *pDst, uint32_t batch, void *stream)
 {
   if (!S || !pSrc || !pDst) { set_error("arm_rfft_q31_dev: null argument"); return ARM_MATH_ARGUMENT_ERROR; }
+  if (!aligned16(pSrc, "arm_rfft_q31_dev") || !aligned16(pDst, "arm_rfft_q31_dev")) return ARM_MATH_ARGUMENT_ERROR;
   const int l = rfft_fixed_log(S->fftLenReal);
   if (l < 0) { set_error("arm_rfft_q31_dev: unsupported fftLenReal %u", S->fftLenReal); return ARM_MATH_ARGUMENT_ERROR; }
   const int32_t *tw = dev_tw_q31(l - 1), *rc = dev_rc31(l);
@@ -797,6 +835,7 @@ arm_status arm_cfft_u32_f32_dev(const arm_cfft_instance_u32_f32 *S, float32_t *p
                                 void *stream)
 {
   if (!S || !p) { set_error("arm_cfft_u32_f32_dev: null argument"); return ARM_MATH_ARGUMENT_ERROR; }
+  if (!aligned16(p, "arm_cfft_u32_f32_dev") || (work && !aligned16(work, "arm_cfft_u32_f32_dev"))) return ARM_MATH_ARGUMENT_ERROR;
   if (!is_pow2(S->fftLen)) { set_error("arm_cfft_u32_f32_dev: unsupported fftLen %u", S->fftLen); return ARM_MATH_ARGUMENT_ERROR; }
   int l = ilog2u(S->fftLen);
   if (l >= kMinLog && l <= kMaxLog) {
@@ -854,6 +893,7 @@ ARMFFT_INIT_N(64, q15) ARMFFT_INIT_N(32, q15) ARMFFT_INIT_N(16, q15)
 arm_status arm_cfft_q15_dev(const arm_cfft_instance_q15 *S, q15_t *p, uint32_t batch, uint8_t ifft, uint8_t bitrev, void *stream)
 {
   if (!S || !p) { set_error("arm_cfft_q15_dev: null argument"); return ARM_MATH_ARGUMENT_ERROR; }
+  if (!aligned16(p, "arm_cfft_q15_dev")) return ARM_MATH_ARGUMENT_ERROR;
   int l = cfft_log(S->fftLen);
   if (l < 0) { set_error("arm_cfft_q15_dev: unsupported fftLen %u", (unsigned)S->fftLen); return ARM_MATH_ARGUMENT_ERROR; }
   const int16_t *tw = dev_tw_q15(l);
@@ -895,6 +935,7 @@ ARMFFT_INIT_N(32, q31) ARMFFT_INIT_N(16, q31)
 arm_status arm_cfft_q31_dev(const arm_cfft_instance_q31 *S, q31_t *p, uint32_t batch, uint8_t ifft, uint8_t bitrev, void *stream)
 {
   if (!S || !p) { set_error("arm_cfft_q31_dev: null argument"); return ARM_MATH_ARGUMENT_ERROR; }
+  if (!aligned16(p, "arm_cfft_q31_dev")) return ARM_MATH_ARGUMENT_ERROR;
   int l = cfft_log(S->fftLen);
   if (l < 0) { set_error("arm_cfft_q31_dev: unsupported fftLen %u", (unsigned)S->fftLen); return ARM_MATH_ARGUMENT_ERROR; }
   const int32_t *tw = dev_tw_q31(l);
@@ -946,6 +987,7 @@ arm_status arm_rfft_fast_f32_dev(const arm_rfft_fast_instance_f32 *S, const floa
                                  uint8_t ifft, void *stream)
 {
   if (!S || !p || !pOut) { set_error("arm_rfft_fast_f32_dev: null argument"); return ARM_MATH_ARGUMENT_ERROR; }
+  if (!aligned16(p, "arm_rfft_fast_f32_dev") || !aligned16(pOut, "arm_rfft_fast_f32_dev")) return ARM_MATH_ARGUMENT_ERROR;
   int l = rfft_log(S);
   if (l < 0) { set_error("arm_rfft_fast_f32_dev: unsupported instance"); return ARM_MATH_ARGUMENT_ERROR; }
   if (p == pOut) { set_error("arm_rfft_fast_f32_dev: input and output must be different buffers"); return ARM_MATH_ARGUMENT_ERROR; }

@@ -381,7 +381,7 @@ __device__ __forceinline__ void run_stages(typename Q::word *lds, TWP tw, int ba
 }
 
 // One group of TPB transforms: global -> LDS, all stages, LDS -> global.  TWP = pointer to the twiddle
-// table, in global memory or (persistent variant) in LDS.
+// table in global memory, TWL = optional LDS copy of every fourth entry (FixedTune::TW4).
 template <class Q, int LOGN, bool INV, class TWP, class TWL = NoTl>
 __device__ __forceinline__ void fixed_one_group(typename Q::word *__restrict__ data, TWP tw, typename Q::word *lds, uint32_t batch,
                                                 uint32_t g, int bitrev, int tid, TWL tl = TWL())
@@ -447,16 +447,15 @@ __device__ __forceinline__ void fixed_one_group(typename Q::word *__restrict__ d
   }
 }
 
-// Persistent variant for the sizes where it pays (FixedTune): the 3N/4-entry twiddle table is copied to
-// LDS once per workgroup and the workgroup loops over groups of transforms.  The per-butterfly twiddle
-// reads are gathers (every lane its own entry): from global memory each costs one L1 line per lane.
-template <class Q, int LOGN> struct FixedTune { static constexpr int WGPCU = 0; static constexpr bool TW4 = false; };
-// TW4: one transform per workgroup, every fourth table entry copied to LDS first (3N/16 entries, 6 KiB
-// at 4096 q31 points: still four workgroups per CU): only stage 0 gathers its twiddles from global memory
-// q15: 1024 +10 %, 2048 +17 %, 8192 +23 %, 16384 +47 %; 4096: 3.45 TB/s against 2.87 for the persistent form
-// with the WHOLE table in LDS (WGPCU = 5), which no size selects any more
-template <int LOGN> struct FixedTune<Q15, LOGN> { static constexpr int WGPCU = 0; static constexpr bool TW4 = (LOGN >= 10); };
-template <int LOGN> struct FixedTune<Q31, LOGN> { static constexpr int WGPCU = 0; static constexpr bool TW4 = (LOGN == 12 || LOGN == 13); };  // measured: 4096 +12 %, 8192 +15 %, 1024/2048 -2.5 %
+// Per-size tuning.  TW4: every fourth entry of the 3N/4-entry twiddle table is copied to LDS first
+// (3N/16 entries, 6 KiB at 4096 q31 points: still four workgroups per CU).  All stages after the first
+// index the table in multiples of 4 (twidCoefModifier 4^S), so only stage 0 gathers its twiddles from
+// global memory (a gather costs one L1 line per lane there).  Same-box A/B: q15 1024 +10 %, 2048 +17 %,
+// 8192 +23 %, 16384 +47 %, 4096 3.45 TB/s (against 2.87 for an earlier persistent form that kept the
+// WHOLE table in LDS; removed); q31 4096 +12 %, 8192 +15 %, 1024 / 2048 -2.5 % (left on global gathers).
+template <class Q, int LOGN> struct FixedTune { static constexpr bool TW4 = false; };
+template <int LOGN> struct FixedTune<Q15, LOGN> { static constexpr bool TW4 = (LOGN >= 10); };
+template <int LOGN> struct FixedTune<Q31, LOGN> { static constexpr bool TW4 = (LOGN == 12 || LOGN == 13); };
 
 template <class Q, int LOGN, bool INV>
 __global__ __launch_bounds__(FixedPlan<LOGN>::T, 4) void cfft_fixed_kernel(typename Q::word *__restrict__ data,
@@ -470,18 +469,7 @@ __global__ __launch_bounds__(FixedPlan<LOGN>::T, 4) void cfft_fixed_kernel(typen
   word *lds = reinterpret_cast<word *>(lds_raw);
   const uint32_t g0 = blockIdx.x + blockIdx.y * gridDim.x;
   if (g0 >= ngroups) return;
-  if constexpr (FixedTune<Q, LOGN>::WGPCU > 0) {
-    tword *tl = reinterpret_cast<tword *>(lds + PL::LDS_WORDS);
-    for (int i = threadIdx.x; i < 3 * PL::N / 4; i += PL::T) tl[i] = tw[i];
-    __syncthreads();
-    const uint32_t gstep = gridDim.x * gridDim.y;
-    for (uint32_t g = g0; g < ngroups; g += gstep) {
-      int tid = threadIdx.x;
-      asm volatile("" : "+v"(tid));  // keep the per-thread address math inside the loop
-      fixed_one_group<Q, LOGN, INV>(data, (const tword *)tl, lds, batch, g, bitrev, tid);
-      __syncthreads();
-    }
-  } else if constexpr (FixedTune<Q, LOGN>::TW4) {
+  if constexpr (FixedTune<Q, LOGN>::TW4) {
     tword *tl = reinterpret_cast<tword *>(lds + PL::LDS_WORDS);
     for (int i = threadIdx.x; i < 3 * PL::N / 16; i += PL::T) tl[i] = tw[4 * i];
     // (the barrier after the data load inside fixed_one_group orders these writes before the stages)
@@ -532,8 +520,7 @@ template <class Q, int LOGN, bool INV>
 static hipError_t launch_fixed_one(typename Q::word *data, const typename Q::tword *tw, uint32_t batch, bool bitrev, hipStream_t stream)
 {
   using PL = FixedPlan<LOGN>;
-  constexpr int WGPCU = FixedTune<Q, LOGN>::WGPCU;
-  constexpr size_t lds_bytes = (size_t)PL::LDS_WORDS * sizeof(typename Q::word) + (WGPCU ? (size_t)(3 * PL::N / 4) * sizeof(typename Q::tword) : 0) +
+  constexpr size_t lds_bytes = (size_t)PL::LDS_WORDS * sizeof(typename Q::word) +
                                (FixedTune<Q, LOGN>::TW4 ? (size_t)(3 * PL::N / 16) * sizeof(typename Q::tword) : 0);
   static std::atomic<bool> attr_done[16];  // zero-initialised; a racing second hipFuncSetAttribute is harmless
   int dev = 0;
@@ -545,13 +532,7 @@ static hipError_t launch_fixed_one(typename Q::word *data, const typename Q::two
     attr_done[dev] = true;
   }
   const uint32_t ngroups = (batch + PL::TPB - 1) / PL::TPB;
-  uint32_t gx = ngroups < 65536u ? ngroups : 65536u, gy = (ngroups + gx - 1) / gx;
-  if (WGPCU) {
-    int cus = 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    const uint32_t resident = (uint32_t)(WGPCU * cus);
-    if (ngroups > resident) { gx = resident; gy = 1; }
-  }
+  const uint32_t gx = ngroups < 65536u ? ngroups : 65536u, gy = (ngroups + gx - 1) / gx;
   kern<<<dim3(gx, gy, 1), PL::T, lds_bytes, stream>>>(data, tw, batch, ngroups, bitrev ? 1 : 0);
   return hipGetLastError();
 }

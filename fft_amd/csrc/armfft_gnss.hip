@@ -19,6 +19,7 @@
 // find_top2_peaks_cplx (gnss_codes.c:1144-1166) is a sequential scan whose second peak depends on
 // which index was the running best when each sample was seen; top2_scan() below reproduces it
 // exactly (values and indices, ties included) with a workgroup prefix scan.
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -654,12 +655,25 @@ struct gnss_acq_plan {
 
 namespace {
 
+// hipFuncSetAttribute once per kernel and device (the f32 / fixed / large launchers do the same): `done`
+// is the caller's function-local static, one per template instantiation, zero-initialised; a racing
+// second call is harmless.
+template <class K>
+hipError_t lds_attr_once(K kern, size_t bytes, std::atomic<bool> *done, int dev)
+{
+  if (bytes <= 48 * 1024 || (dev >= 0 && dev < 16 && done[dev].load(std::memory_order_relaxed))) return hipSuccess;
+  hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e == hipSuccess && dev >= 0 && dev < 16) done[dev].store(true, std::memory_order_relaxed);
+  return e;
+}
+
 template <int LOGN>
 hipError_t launch_spectrum(const gnss_acq_plan *pl, hipStream_t s)
 {
   using PL = GPlan<LOGN>;
   auto k = gnss_code_spectrum_kernel<LOGN>;
-  hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PL::LDS_BYTES);
+  static std::atomic<bool> done[16];
+  hipError_t e = lds_attr_once(k, PL::LDS_BYTES, done, pl->device);
   if (e != hipSuccess) return e;
   k<<<pl->n_prn, PL::T, PL::LDS_BYTES, s>>>(pl->chips_dev, pl->spectra_dev, pl->tw, pl->spm, pl->spc);
   return hipGetLastError();
@@ -672,7 +686,8 @@ hipError_t launch_acquire(const gnss_acq_plan *pl, const void *sig, int packed, 
   using PL = GPlan<LOGN>;
   const size_t lds = PL::LDS_BYTES + 3 * ((PL::T + 63) / 64) * 8 + 16 + kMaxMs * sizeof(float2);
   auto k = gnss_acquire_kernel<LOGN>;
-  hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  static std::atomic<bool> done[16];
+  hipError_t e = lds_attr_once(k, lds, done, pl->device);
   if (e != hipSuccess) return e;
   k<<<dim3(d1 - d0, n_scenes), PL::T, lds, s>>>(sig, packed, pl->spectra_dev, pl->tw, pl->dops_dev, pl->prns_dev, pl->n_prn, pl->n_dop, d0,
                                                 pl->n_ms, pl->spm, pl->fs_hz, pl->pk_sep, all);
@@ -687,18 +702,19 @@ hipError_t launch_groups(const gnss_acq_plan *pl, const void *sig, int packed, u
   const size_t lds_a = PL::LDS_BYTES + kMaxMs * sizeof(float2);
   const size_t lds_b = PL::LDS_BYTES + 3 * ((PL::T + 63) / 64) * 8 + 16;
   auto ka = gnss_group_spectra_kernel<LOGN>;
-  hipError_t e = hipFuncSetAttribute((const void *)ka, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a);
+  static std::atomic<bool> done_a[16], done_b1[16], done_b2[16];
+  hipError_t e = lds_attr_once(ka, lds_a, done_a, pl->device);
   if (e != hipSuccess) return e;
   ka<<<dim3(d1 - d0, n_scenes, n_groups), PL::T, lds_a, s>>>(sig, packed, pl->tw, pl->dops_dev, d0, pl->n_ms, pl->n_ms / n_groups, pl->spm,
                                                              pl->fs_hz, work);
   if ((e = hipGetLastError()) != hipSuccess) return e;
   if (mode == 1) {
     auto kb = gnss_accumulate_kernel<LOGN, 1>;
-    if ((e = hipFuncSetAttribute((const void *)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b)) != hipSuccess) return e;
+    if ((e = lds_attr_once(kb, lds_b, done_b1, pl->device)) != hipSuccess) return e;
     kb<<<dim3(d1 - d0, n_scenes), PL::T, lds_b, s>>>(work, pl->spectra_dev, pl->tw, pl->prns_dev, pl->n_prn, pl->n_dop, d0, n_groups, pl->pk_sep, all);
   } else {
     auto kb = gnss_accumulate_kernel<LOGN, 2>;
-    if ((e = hipFuncSetAttribute((const void *)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b)) != hipSuccess) return e;
+    if ((e = lds_attr_once(kb, lds_b, done_b2, pl->device)) != hipSuccess) return e;
     kb<<<dim3(d1 - d0, n_scenes), PL::T, lds_b, s>>>(work, pl->spectra_dev, pl->tw, pl->prns_dev, pl->n_prn, pl->n_dop, d0, n_groups, pl->pk_sep, all);
   }
   return hipGetLastError();
@@ -900,18 +916,32 @@ arm_status gnss_acquire(gnss_acq_plan *pl, const float *signal, uint32_t n_scene
 }
 
 // ---- per-function probes (device pointers) ----
-static arm_status chips_for(int prn, int8_t **chips)
+// C/A chips of PRN 1..37 on the current device: generated once per device (37 x 1023 bytes, kept for
+// the life of the process) so that the probes below neither allocate nor free per call.
+static arm_status chips_for(int prn, const int8_t **chips)
 {
   if (prn < 1 || prn > 37) { set_error("PRN %d outside 1..37", prn); return ARM_MATH_ARGUMENT_ERROR; }
-  int32_t *p = nullptr;
-  if (!hip_ok(hipMalloc((void **)&p, sizeof(int32_t)), "hipMalloc") || !hip_ok(hipMalloc((void **)chips, kCodeLen), "hipMalloc")) return ARM_MATH_ARGUMENT_ERROR;
-  bool ok = hip_ok(hipMemcpy(p, &prn, sizeof(int32_t), hipMemcpyHostToDevice), "hipMemcpy");
-  if (ok) {
-    gnss_code_kernel<<<1, 256, 0, nullptr>>>(p, *chips);
-    ok = hip_ok(hipGetLastError(), "gnss_code_kernel") && hip_ok(hipStreamSynchronize(nullptr), "synchronise");
+  static std::mutex mu;
+  static int8_t *cache[16];
+  int dev = -1;
+  if (!hip_ok(hipGetDevice(&dev), "hipGetDevice") || dev < 0 || dev >= 16) { if (dev >= 16) set_error("device index %d out of range", dev); return ARM_MATH_ARGUMENT_ERROR; }
+  std::lock_guard<std::mutex> lk(mu);
+  if (!cache[dev]) {
+    int32_t host_prns[37];
+    for (int i = 0; i < 37; i++) host_prns[i] = i + 1;
+    int32_t *p = nullptr;
+    int8_t *c = nullptr;
+    bool ok = hip_ok(hipMalloc((void **)&p, sizeof(host_prns)), "hipMalloc") && hip_ok(hipMalloc((void **)&c, 37 * (size_t)kCodeLen), "hipMalloc") &&
+              hip_ok(hipMemcpy(p, host_prns, sizeof(host_prns), hipMemcpyHostToDevice), "hipMemcpy");
+    if (ok) {
+      gnss_code_kernel<<<37, 256, 0, nullptr>>>(p, c);
+      ok = hip_ok(hipGetLastError(), "gnss_code_kernel") && hip_ok(hipStreamSynchronize(nullptr), "synchronise");
+    }
+    (void)hipFree(p);
+    if (!ok) { (void)hipFree(c); return ARM_MATH_ARGUMENT_ERROR; }
+    cache[dev] = c;
   }
-  (void)hipFree(p);
-  if (!ok) { (void)hipFree(*chips); *chips = nullptr; return ARM_MATH_ARGUMENT_ERROR; }
+  *chips = cache[dev] + (size_t)(prn - 1) * kCodeLen;
   return ARM_MATH_SUCCESS;
 }
 
@@ -968,13 +998,12 @@ arm_status gnss_get_code_dev(int32_t num, int32_t samples_per_chip, int32_t prn,
   if (!out_dev || num < 0) { set_error("gnss_get_code_dev: bad argument"); return ARM_MATH_ARGUMENT_ERROR; }
   if (samples_per_chip < 1) samples_per_chip = 1;  // gnss_codes.c:1010
   if (num == 0) return ARM_MATH_SUCCESS;
-  int8_t *chips = nullptr;
+  const int8_t *chips = nullptr;
   arm_status st = chips_for(prn, &chips);
   if (st != ARM_MATH_SUCCESS) return st;
   const int total = num * samples_per_chip;
   gnss_expand_code_kernel<<<(total + 255) / 256, 256, 0, nullptr>>>(chips, out_dev, total, samples_per_chip);
   bool ok = hip_ok(hipGetLastError(), "gnss_expand_code_kernel") && hip_ok(hipStreamSynchronize(nullptr), "synchronise");
-  (void)hipFree(chips);
   return ok ? ARM_MATH_SUCCESS : ARM_MATH_ARGUMENT_ERROR;
 }
 
@@ -982,13 +1011,12 @@ arm_status gnss_synth_gps_prn_dev(int32_t prn, float doppler, uint32_t size, flo
 {
   if (!replica_dev || samples_per_chip < 1) { set_error("gnss_synth_gps_prn_dev: bad argument"); return ARM_MATH_ARGUMENT_ERROR; }
   if (size == 0) return ARM_MATH_SUCCESS;
-  int8_t *chips = nullptr;
+  const int8_t *chips = nullptr;
   arm_status st = chips_for(prn, &chips);
   if (st != ARM_MATH_SUCCESS) return st;
   gnss_replica_kernel<<<(size + 255) / 256, 256, 0, nullptr>>>(chips, reinterpret_cast<float2 *>(replica_dev), (int)size, samples_per_chip,
                                                                (double)doppler, 0.0);
   bool ok = hip_ok(hipGetLastError(), "gnss_replica_kernel") && hip_ok(hipStreamSynchronize(nullptr), "synchronise");
-  (void)hipFree(chips);
   return ok ? ARM_MATH_SUCCESS : ARM_MATH_ARGUMENT_ERROR;
 }
 

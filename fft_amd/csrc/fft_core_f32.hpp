@@ -110,9 +110,13 @@ __device__ __forceinline__ void butterfly<16>(float2 *v)
 }
 
 // ---- compile-time plan ----
-// Plan<LOGN, TT>: TT threads per workgroup (0 = default: 256 below 4096 points, N/16 above).
-template <int LOGN_, int TT = 0>
+// Plan<LOGN, TT, PP>: TT threads per workgroup (0 = default: 256 below 4096 points, N/16 above).
+// PP: two LDS images used alternately (pass p writes image p & 1), which removes the barrier between
+// a middle pass's reads and its writes -- for kernels that run few workgroups per CU and have the
+// LDS to spare.
+template <int LOGN_, int TT = 0, bool PP = false>
 struct Plan {
+  static constexpr bool PINGPONG = PP;
   static constexpr int E = 16;  // points per thread and pass
   static constexpr int LOGN = LOGN_;
   static constexpr int N = 1 << LOGN;
@@ -131,7 +135,8 @@ struct Plan {
   // 8-byte reads conflict-free or 2-way) and skewed by 2 more points per sequence so that
   // accesses that walk ACROSS sequences (tile staging, transposes) spread over the banks.
   static constexpr int SEQ_STRIDE = N + (N >> 4) * 2 + (TPB > 1 ? 2 : 0);
-  static constexpr int LDS_ELEMS = TPB * SEQ_STRIDE;
+  static constexpr int BUF_ELEMS = TPB * SEQ_STRIDE;
+  static constexpr int LDS_ELEMS = (PP ? 2 : 1) * BUF_ELEMS;
   static constexpr size_t LDS_BYTES = (size_t)LDS_ELEMS * sizeof(float2);
   // LDS index of point e of sequence t
   static __device__ __forceinline__ int idx(int t, int e) { return t * SEQ_STRIDE + e + ((e >> 4) << 1); }
@@ -389,6 +394,9 @@ __device__ __forceinline__ void fft_pass(float2 *v, float2 *lds, const TW &tw, i
   constexpr int LNS = PL::lns(P), NS = 1 << LNS;
   constexpr int LNR = LOGN - LR;  // log2(N/R): butterflies per transform
   constexpr bool FIRST = (P == 0), LAST = (P == PL::NPASS - 1);
+  // ping-pong plans: pass p reads the image pass p - 1 wrote and writes the other one
+  const float2 *src = lds + ((PL::PINGPONG && !FIRST && ((P - 1) & 1)) ? PL::BUF_ELEMS : 0);
+  float2 *dst = lds + ((PL::PINGPONG && (P & 1)) ? PL::BUF_ELEMS : 0);
 
   // ---- gather ----
 #pragma unroll
@@ -401,7 +409,7 @@ __device__ __forceinline__ void fft_pass(float2 *v, float2 *lds, const TW &tw, i
       if constexpr (FIRST) {
         if constexpr (!std::is_same<Load, Preloaded>::value) v[q * R + r] = ld(t, j + (r << LNR));
       } else {
-        v[q * R + r] = lds[base + PL::delta(r << LNR)];
+        v[q * R + r] = src[base + PL::delta(r << LNR)];
       }
     }
   }
@@ -427,7 +435,7 @@ __device__ __forceinline__ void fft_pass(float2 *v, float2 *lds, const TW &tw, i
   for (int q = 0; q < NB; q++) butterfly<R>(v + q * R);
   // ---- scatter ----
   // source and destination both in LDS: every read of this pass must finish before any write
-  if ((!FIRST || LDS_IN) && (!LAST || LDS_OUT)) __syncthreads();
+  if ((!FIRST || LDS_IN) && (!LAST || LDS_OUT) && !(PL::PINGPONG && !FIRST && !LAST)) __syncthreads();
 #pragma unroll
   for (int q = 0; q < NB; q++) {
     const int w = tid + q * T;
@@ -446,13 +454,13 @@ __device__ __forceinline__ void fft_pass(float2 *v, float2 *lds, const TW &tw, i
       const int base = PL::idx(t, j * R);
 #pragma unroll
       for (int r = 0; r < R; r += 2) {
-        *reinterpret_cast<float4 *>(&lds[base + PL::delta(r)]) =
+        *reinterpret_cast<float4 *>(&dst[base + PL::delta(r)]) =
             make_float4(v[q * R + r].x, v[q * R + r].y, v[q * R + r + 1].x, v[q * R + r + 1].y);
       }
     } else {
       const int base = PL::idx(t, j0);
 #pragma unroll
-      for (int r = 0; r < R; r++) lds[base + PL::delta(r << LNS)] = v[q * R + r];
+      for (int r = 0; r < R; r++) dst[base + PL::delta(r << LNS)] = v[q * R + r];
     }
   }
   if constexpr (!LAST && !TW::lazy(LAST ? P : P + 1)) {

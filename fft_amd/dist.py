@@ -65,6 +65,28 @@ def merge_best(best, group=None):
     return torch.gather(rows, 0, win[None, :, None].expand(1, rows.shape[1], ACQ_WORDS))[0]
 
 
+def sharded_acquire(acquire, n_dop, n_rows, rank=None, world=None, row_prns=None, device=None, group=None):
+    """One Doppler-sharded acquisition step, as `bench.py --gnss-shard doppler` and a multi-GPU
+    caller of gnss_acquire_dev run it: this rank searches its share [d0, d1) of the plan's n_dop
+    bins through `acquire(d0, d1)` -- which returns the rank's winners as an int32 tensor
+    [n_rows, 8] (n_rows = scenes x PRNs; doppler_bin holds GLOBAL bin indices, as
+    gnss_acquire_dev writes them) -- and the winners of all ranks are merged by ONE all-gather
+    (`merge_best`).  A rank whose share is empty contributes `empty_best` rows and still takes
+    part in the collective.  Returns (merged [n_rows, 8], (d0, d1)); merged is identical on
+    every rank and equal to the single-rank search over all bins."""
+    import torch.distributed as dist
+
+    if rank is None or world is None:
+        on = dist.is_available() and dist.is_initialized()
+        rank = dist.get_rank(group) if on else 0
+        world = dist.get_world_size(group) if on else 1
+    d0, d1 = doppler_range(n_dop, rank, world)
+    mine = acquire(d0, d1) if d1 > d0 else empty_best(n_rows, row_prns, device)
+    if tuple(mine.shape) != (n_rows, ACQ_WORDS):
+        raise ValueError("acquire() must return an int32 tensor [%d, %d], got %r" % (n_rows, ACQ_WORDS, tuple(mine.shape)))
+    return merge_best(mine, group), (d0, d1)
+
+
 def empty_best(n_prn, prns=None, device=None):
     """The tuple list of a rank that searched nothing (peak = -1, indices -1)."""
     import torch

@@ -13,6 +13,14 @@
  *     (rfft: p + fftLenRFFT*b, pOut + fftLenRFFT*b);
  *   - host-pointer entry points copy in and out synchronously; *_dev entry points take device
  *     pointers and a hipStream_t (as void*), launch asynchronously and never allocate;
+ *   - every device data pointer handed to a *_dev entry point must be 16-byte aligned (hipMalloc
+ *     and torch allocations are; the kernels use 16-byte vector accesses): a misaligned pointer is
+ *     refused with ARM_MATH_ARGUMENT_ERROR, nothing is launched;
+ *   - the reference's own entry points return void (arm_cfft_f32, arm_cfft_q15, arm_cfft_q31,
+ *     arm_rfft_fast_f32, arm_rfft_q15/q31, arm_cfft_radix2_f32, up_sample_*): when the GPU cannot
+ *     run them (no device, a failed HIP call, staging memory exhausted) they print the reason to
+ *     stderr and abort() rather than return unprocessed data.  A C caller that wants to handle such
+ *     failures calls the status-returning *_batch_* twin (batch = 1) instead;
  *   - instances are caller-owned PODs; pTwiddle / pBitRevTable point to valid HOST tables owned
  *     by the library (static lifetime), device plans are cached inside the library per GPU.
  */

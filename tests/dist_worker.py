@@ -23,14 +23,16 @@ def run(rank, world, port, out_dir):
         # --- GNSS: Doppler bins of one scene sharded over the ranks, one small collective ---
         sig = H.make_gps_scene(n_ms=2, sigma=1.0)
         prns = H.ALL_PRNS[:12]
-        d0, d1 = D.doppler_range(len(H.DOPPLER_GRID), rank, world)
-        if d1 > d0:
+
+        def acquire(d0, d1):   # what gnss_acquire_dev(dop_begin, dop_end, best_dev) returns on a GPU rank
             best, _ = H.oracle_acquire(sig, 2, 4092, 4096, 4, prns, H.DOPPLER_GRID[d0:d1], want_all=False)
             best["doppler_bin"] += d0                      # local -> global bin index
-            mine = torch.from_numpy(best.view(np.int32).reshape(len(prns), 8).copy())
-        else:
-            mine = D.empty_best(len(prns), prns)
-        merged = D.merge_best(mine).numpy()
+            return torch.from_numpy(best.view(np.int32).reshape(len(prns), 8).copy())
+
+        # the step bench.py --gnss-shard doppler times (fft_amd.dist.sharded_acquire), group taken from the env
+        merged, (d0, d1) = D.sharded_acquire(acquire, len(H.DOPPLER_GRID), len(prns), row_prns=prns)
+        assert (d0, d1) == D.doppler_range(len(H.DOPPLER_GRID), rank, world)
+        merged = merged.numpy()
         np.save(os.path.join(out_dir, "merged_%d.npy" % rank), merged)
         # --- batched transforms: contiguous slices, no collective; only the timing reduction of bench.py ---
         b0, b1 = D.batch_slice(1000, rank, world)

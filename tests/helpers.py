@@ -134,8 +134,10 @@ RFFT_KNOWN_MISS = {(4096, "step"): ("all", 1.5e-4)}
 
 
 def rel_l2(test_v, ref_v):
-    test_v = np.asarray(test_v, dtype=np.float64)
-    ref_v = np.asarray(ref_v, dtype=np.float64)
+    """Relative L2 error; complex inputs keep their imaginary parts (complex128), real ones go to float64."""
+    test_v, ref_v = np.asarray(test_v), np.asarray(ref_v)
+    wide = np.complex128 if (np.iscomplexobj(test_v) or np.iscomplexobj(ref_v)) else np.float64
+    test_v, ref_v = test_v.astype(wide), ref_v.astype(wide)
     return np.linalg.norm(test_v - ref_v) / max(np.linalg.norm(ref_v), 1e-300)
 
 

@@ -124,4 +124,4 @@ def test_cfft_large_host_batch_and_errors():
     assert fft_amd.lib.arm_cfft_u32_f32_dev(ctypes.byref(S), ctypes.c_void_p(t.data_ptr()), ctypes.c_void_p(t.data_ptr()), 1, 0,
                                             None) == fft_amd.ARM_MATH_ARGUMENT_ERROR
     # empty batch: no-op
-    G.check(fft_amd.lib.arm_cfft_u32_f32_dev(ctypes.byref(S), ctypes.c_void_p(t.data_ptr()), ctypes.c_void_p(t.data_ptr() + 8), 0, 0, None))
+    G.check(fft_amd.lib.arm_cfft_u32_f32_dev(ctypes.byref(S), ctypes.c_void_p(t.data_ptr()), ctypes.c_void_p(t.data_ptr() + 16), 0, 0, None))

@@ -412,3 +412,40 @@ def test_f32_ragged_tail_writes_nothing_past_the_batch(n):
         assert np.all(out[batch:] == 777.0)
         assert np.array_equal(out[:batch], G.rfft_dev(xr[:batch], n, ifft)[0])
         assert np.array_equal(ti.cpu().numpy(), xr)
+
+
+@pytest.mark.gpu
+def test_dev_entry_points_refuse_misaligned_device_pointers():
+    """include/arm_fft_mi355.h: device data pointers of the *_dev entry points are 16-byte aligned.
+    ptr + 8 is refused with ARM_MATH_ARGUMENT_ERROR before anything is launched (the kernels use
+    16-byte vector accesses; a misaligned one would fault the GPU), and the data stay untouched."""
+    import torch
+    import fft_amd
+    G = _gpu()
+    lib, ERR = fft_amd.lib, fft_amd.ARM_MATH_ARGUMENT_ERROR
+    t = torch.arange(4096, device="cuda", dtype=torch.float32)
+    o = torch.zeros(4096, device="cuda", dtype=torch.float32)
+    keep = t.clone()
+    good, bad, obad = t.data_ptr(), t.data_ptr() + 8, o.data_ptr() + 8
+    assert good % 16 == 0
+    vp = ctypes.c_void_p
+    for kind in ("f32", "q15", "q31"):
+        S = G.cfft_inst(kind, 32)
+        assert getattr(lib, "arm_cfft_%s_dev" % kind)(ctypes.byref(S), vp(bad), 1, 0, 1, G.stream_ptr()) == ERR
+        assert "16-byte aligned" in fft_amd.last_error()
+    R = G.rfft_inst(64)
+    assert lib.arm_rfft_fast_f32_dev(ctypes.byref(R), vp(bad), vp(o.data_ptr()), 1, 0, G.stream_ptr()) == ERR
+    assert lib.arm_rfft_fast_f32_dev(ctypes.byref(R), vp(good), vp(obad), 1, 0, G.stream_ptr()) == ERR
+    S2 = fft_amd.arm_cfft_radix2_instance_f32()
+    G.check(lib.arm_cfft_radix2_init_f32(ctypes.byref(S2), 64, 0, 1))
+    assert lib.arm_cfft_radix2_f32_dev(ctypes.byref(S2), vp(bad), 1, G.stream_ptr()) == ERR
+    for kind, inst in (("q15", fft_amd.arm_rfft_instance_q15), ("q31", fft_amd.arm_rfft_instance_q31)):
+        F = inst()
+        G.check(getattr(lib, "arm_rfft_init_" + kind)(ctypes.byref(F), 64, 0, 1))
+        assert getattr(lib, "arm_rfft_%s_dev" % kind)(ctypes.byref(F), vp(bad), vp(o.data_ptr()), 1, G.stream_ptr()) == ERR
+        assert getattr(lib, "arm_rfft_%s_dev" % kind)(ctypes.byref(F), vp(good), vp(obad), 1, G.stream_ptr()) == ERR
+    U = fft_amd.arm_cfft_instance_u32_f32()
+    G.check(lib.arm_cfft_init_u32_f32(ctypes.byref(U), 64))
+    assert lib.arm_cfft_u32_f32_dev(ctypes.byref(U), vp(bad), None, 1, 0, G.stream_ptr()) == ERR
+    torch.cuda.synchronize()
+    assert torch.equal(t, keep) and not o.any()

@@ -81,12 +81,18 @@ def test_cfft_q31_golden(n, sig, rounding):
 
 def test_f64_truth_matches_numpy():
     r = H.rng(7)
-    for n in (16, 1024, 16384):
+    # 2^15 and 2^17: the sizes at which tests/test_gpu_large.py judges the four-step kernels by this oracle
+    for n in (16, 1024, 16384, 1 << 15, 1 << 17):
         x = r.uniform(-1, 1, 2 * n)
-        y = x.copy()
-        assert H.oracle().orc_cfft_f64(ptr(y, H.c_d), n, 0) == 0
-        want = np.fft.fft(x[0::2] + 1j * x[1::2])
-        assert H.rel_l2(y[0::2] + 1j * y[1::2], want) < 1e-13
+        for inv in (0, 1):
+            y = x.copy()
+            assert H.oracle().orc_cfft_f64(ptr(y, H.c_d), n, inv) == 0
+            z = x[0::2] + 1j * x[1::2]
+            want = np.fft.ifft(z) if inv else np.fft.fft(z)
+            got = y[0::2] + 1j * y[1::2]
+            assert H.rel_l2(got, want) < 1e-13
+            # both components separately (a complex-blind comparison once hid the imaginary part)
+            assert H.rel_l2(got.real, want.real) < 1e-12 and H.rel_l2(got.imag, want.imag) < 1e-12
 
 
 def test_oracle_rejects_sizes_outside_reference_range():
