@@ -15,7 +15,20 @@ Extra objects on that line:
                   / average launch duration measured with HIP events on the launch stream.
   cpu_baseline -- the reference's own generic-C arm_cfft_f32 (oracle/_ref, kind "reference") or,
                   when that library was not built, the repo's CPU restatement (kind "port"),
-                  timed on a bounded sample on this host's cores (rank 0, N = 1 only).
+                  timed on a bounded sample on this host's cores (rank 0, N = 1 only).  `rows` holds
+                  the SURVEY 8(d) table: 1 core and all cores, the -O2 build and the -O3 AVX2 build of
+                  oracle/_ref, streaming (distinct buffers) and cache-resident (one 32 KiB buffer),
+                  each the median of 5 repeats.
+  extra        -- (N = 1 only) the other BASELINE.json configs measured the same way in the same run,
+                  a few steps each: cfft_q15 / cfft_q31 4096x65536, rfft_f32 16384x16384, the four-step
+                  2^22 x 8 and GNSS acquisition x256; each entry carries value, ms_per_step and its own
+                  roofline object.  The headline `value` / `roofline` stay those of config 2.
+
+`--workload gnss_acq_gps_l1_x256 --gnss-shard doppler` times the OTHER way the GNSS search shards
+(SURVEY 8e): every rank holds all scenes, searches its share of the 41 Doppler bins
+(gnss_acquire_dev(dop_begin, dop_end)) and the per-(scene, PRN) winners are merged by one RCCL
+all-gather per step (fft_amd.dist.sharded_acquire); the merged tuples are checked against the
+single-rank search of all bins after the timed region ("scaling": "strong").
 """
 import argparse
 import ctypes
@@ -52,6 +65,10 @@ def parse():
                     help="one of %s, or <cfft_f32|cfft_q15|cfft_q31|rfft_f32>_<N>x<batch> for tuning runs" % ", ".join(sorted(WORKLOADS)))
     ap.add_argument("--batch", type=int, default=0, help="override the batch (debug only; the line says so)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the other configs' measurements (headline workload, N = 1)")
+    ap.add_argument("--extra-steps", type=int, default=5)
+    ap.add_argument("--gnss-shard", choices=["scenes", "doppler"], default="scenes",
+                    help="GNSS workload, N > 1: scenes per rank (no collective) or Doppler bins per rank + one all-gather per step")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -59,9 +76,54 @@ def parse():
 # ---------------------------------------------------------------------------------------------
 # CPU baseline (checker code, timed beside the GPU number; never part of the measured GPU path)
 # ---------------------------------------------------------------------------------------------
+def _cpu_has_avx2():
+    try:
+        flags = open("/proc/cpuinfo").read().split("flags", 1)[1].split("\n", 1)[0].split()
+    except Exception:
+        return False
+    return all(f in flags for f in ("avx2", "fma", "bmi2", "movbe", "f16c"))
+
+
+def _cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown CPU"
+
+
+def _timed_rate(call, proto, threads, per_call, seconds):
+    """transforms/s over `threads` threads, each with its own copy of `proto` (refreshed, untimed, before every call:
+    repeated in-place FFTs overflow); only the calls are timed."""
+    import numpy as np
+    busy = [0.0] * threads
+    done = [0] * threads
+    deadline = time.perf_counter() + seconds
+
+    def worker(i):
+        work = proto.copy()
+        call(work)  # warm-up (tables, caches)
+        while time.perf_counter() < deadline:
+            np.copyto(work, proto)
+            t0 = time.perf_counter()
+            call(work)
+            busy[i] += time.perf_counter() - t0
+            done[i] += per_call
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(threads)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    return sum(done[i] / busy[i] for i in range(threads) if busy[i] > 0), sum(done)
+
+
 def cpu_baseline(kind, n, seconds):
     import numpy as np
     ref_so = os.path.join(ROOT, "oracle", "_ref", "libcmsis_ref.so")
+    ref_o3_so = os.path.join(ROOT, "oracle", "_ref", "libcmsis_ref_o3.so")
     orc_so = os.path.join(ROOT, "oracle", "liboracle.so")
     if kind == "large":
         return cpu_baseline_large(n, seconds)
@@ -80,67 +142,87 @@ def cpu_baseline(kind, n, seconds):
     cores = max(1, min(16, os.cpu_count() or 1))
     per_thread = 256  # transforms per call per thread
     rng = np.random.default_rng(0x5EED0001)
-    if kind == "f32":
-        cn = min(n, 4096) if which == "reference" else n
-        proto = rng.uniform(-1, 1, (per_thread, 2 * cn)).astype(np.float32)
-        if which == "reference":
-            call = lambda a: L.ref_cfft_f32(a.ctypes.data_as(ctypes.c_void_p), cn, per_thread, 0, 1)
-        else:
-            call = lambda a: L.orc_cfft_f32_batch(a.ctypes.data_as(ctypes.c_void_p), cn, per_thread, 0, 1)
-        flops = 5.0 * cn * np.log2(cn)
-        sample = "arm_cfft_f32 forward, %d points" % cn
-    elif kind in ("q15", "q31"):
-        dt = np.int16 if kind == "q15" else np.int32
-        amp = 16384 if kind == "q15" else 2 ** 30
-        cn = n
-        proto = rng.integers(-amp, amp, (per_thread, 2 * cn)).astype(dt)
-        if which == "reference":
-            f = getattr(L, "ref_cfft_" + kind)
-            call = lambda a: f(a.ctypes.data_as(ctypes.c_void_p), cn, per_thread, 0, 1)
-        else:
-            f = getattr(L, "orc_cfft_%s_batch" % kind)
-            call = lambda a: f(a.ctypes.data_as(ctypes.c_void_p), cn, per_thread, 0, 1, 0)
-        flops = 5.0 * cn * np.log2(cn)
-        sample = "arm_cfft_%s forward, %d points" % (kind, cn)
-    else:  # rfft: the reference stops at 4096 real points
+    vp = ctypes.c_void_p
+
+    def make(lib, is_ref, count):
+        """(call, proto, flops, sample) for `count` transforms per call on library `lib`"""
+        if kind == "f32":
+            cn = min(n, 4096) if is_ref else n
+            proto = rng.uniform(-1, 1, (count, 2 * cn)).astype(np.float32)
+            if is_ref:
+                call = lambda a: lib.ref_cfft_f32(a.ctypes.data_as(vp), cn, count, 0, 1)
+            else:
+                call = lambda a: lib.orc_cfft_f32_batch(a.ctypes.data_as(vp), cn, count, 0, 1)
+            return call, proto, 5.0 * cn * np.log2(cn), "arm_cfft_f32 forward, %d points" % cn
+        if kind in ("q15", "q31"):
+            dt = np.int16 if kind == "q15" else np.int32
+            amp = 16384 if kind == "q15" else 2 ** 30
+            proto = rng.integers(-amp, amp, (count, 2 * n)).astype(dt)
+            if is_ref:
+                f = getattr(lib, "ref_cfft_" + kind)
+                call = lambda a: f(a.ctypes.data_as(vp), n, count, 0, 1)
+            else:
+                f = getattr(lib, "orc_cfft_%s_batch" % kind)
+                call = lambda a: f(a.ctypes.data_as(vp), n, count, 0, 1, 0)
+            return call, proto, 5.0 * n * np.log2(n), "arm_cfft_%s forward, %d points" % (kind, n)
+        if kind in ("rq15", "rq31"):
+            # fixed-point real FFT: the oracle's restatement of arm_rfft_q15/q31 (one transform per call, looped here)
+            q = kind[1:]
+            dt = np.int16 if q == "q15" else np.int32
+            amp = 16384 if q == "q15" else 2 ** 30
+            proto = rng.integers(-amp, amp, (count, n)).astype(dt)
+            out = np.zeros((2 * n,), dt)
+            f = getattr(lib, "orc_rfft_" + q)
+            # the forward transform clobbers its source like the reference: _timed_rate refreshes it before every call
+
+            def call(a):
+                for i in range(count):
+                    f(a[i].ctypes.data_as(vp), out.ctypes.data_as(vp), n, 0, 1, 0)
+            return call, proto, 2.5 * n * np.log2(n), "arm_rfft_%s forward, %d real points" % (q, n)
+        # rfft f32: the reference stops at 4096 real points
         cn = min(n, 4096)
-        proto = rng.uniform(-1, 1, (per_thread, cn)).astype(np.float32)
+        proto = rng.uniform(-1, 1, (count, cn)).astype(np.float32)
         out = np.zeros_like(proto)
-        if which == "reference":
-            call = lambda a: L.ref_rfft_fast_f32(a.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), cn, per_thread, 0)
+        if is_ref:
+            call = lambda a: lib.ref_rfft_fast_f32(a.ctypes.data_as(vp), out.ctypes.data_as(vp), cn, count, 0)
         else:
-            call = lambda a: L.orc_rfft_fast_f32_batch(a.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), cn, per_thread, 0)
-        flops = 2.5 * cn * np.log2(cn)
-        sample = "arm_rfft_fast_f32 forward, %d real points (reference maximum)" % cn
+            call = lambda a: lib.orc_rfft_fast_f32_batch(a.ctypes.data_as(vp), out.ctypes.data_as(vp), cn, count, 0)
+        return call, proto, 2.5 * cn * np.log2(cn), "arm_rfft_fast_f32 forward, %d real points (reference maximum)" % cn
 
-    busy = [0.0] * cores
-    done = [0] * cores
-    deadline = time.perf_counter() + seconds
-
-    def worker(i):
-        work = proto.copy()
-        call(work)  # warm-up (tables, caches)
-        while time.perf_counter() < deadline:
-            np.copyto(work, proto)  # fresh input each pass (untimed): repeated in-place FFTs overflow
-            t0 = time.perf_counter()
-            call(work)
-            busy[i] += time.perf_counter() - t0
-            done[i] += per_thread
-
-    th = [threading.Thread(target=worker, args=(i,)) for i in range(cores)]
-    for t in th:
-        t.start()
-    for t in th:
-        t.join()
-    rate = sum(done[i] / busy[i] for i in range(cores) if busy[i] > 0)  # transforms/s over all threads
-    return {
+    if kind in ("rq15", "rq31"):
+        if not os.path.exists(orc_so):
+            return None
+        L, which, per_thread = ctypes.CDLL(orc_so), "port", 32
+    call, proto, flops, sample = make(L, which == "reference", per_thread)
+    rate, total = _timed_rate(call, proto, cores, per_thread, seconds * 0.5)
+    res = {
         "value": round(rate * flops / 1e9, 3),
         "unit": "GFLOP/s",
         "cores": cores,
         "kind": which,
-        "sample": "%s; %d threads x %d-transform batches for %.0f s (%d transforms), gcc -O2 scalar C, %.1f us/transform/core"
-                  % (sample, cores, per_thread, seconds, sum(done), 1e6 * cores / rate),
+        "sample": "%s; %d threads x %d-transform batches for %.0f s (%d transforms), gcc -O2 scalar C, %.1f us/transform/core; host: %s"
+                  % (sample, cores, per_thread, seconds * 0.5, total, 1e6 * cores / rate, _cpu_model()),
     }
+    if which != "reference":
+        return res
+    # SURVEY 8(d) rows: 1 core and all cores; -O2 and -O3 (AVX2/FMA) builds of the reference's own sources; distinct
+    # buffers per call (streaming: 256 transforms = 8 MiB per thread at 4096 f32 points) and one cache-resident
+    # transform; each row = median of 5 repeats
+    builds = [("gcc -O2 -ffp-contract=off", L)]
+    if os.path.exists(ref_o3_so) and _cpu_has_avx2():
+        builds.append(("gcc -O3 -march=x86-64-v3 (AVX2+FMA; built where the reference is mounted, so not -march=native of this host)",
+                       ctypes.CDLL(ref_o3_so)))
+    rep_s = max(0.15, seconds * 0.5 / (5.0 * 3 * len(builds)))
+    rows = []
+    for bname, lib in builds:
+        for threads, count, mode in ((1, per_thread, "streaming"), (cores, per_thread, "streaming"), (1, 1, "cache-resident")):
+            c2, p2, fl, _ = make(lib, True, count)
+            rates = sorted(_timed_rate(c2, p2, threads, count, rep_s)[0] for _ in range(5))
+            med = rates[2]
+            rows.append({"build": bname, "cores": threads, "buffers": mode, "value": round(med * fl / 1e9, 3), "unit": "GFLOP/s",
+                         "us_per_transform_per_core": round(1e6 * threads / med, 2), "repeats": 5, "seconds_per_repeat": round(rep_s, 2)})
+    res["rows"] = rows
+    return res
 
 
 def cpu_baseline_large(n, seconds):
@@ -202,6 +284,213 @@ def cpu_baseline_gnss(seconds):
                       "forward FFTs per row, not counted), %.0f s on one core, %.1f us per row" % (rows, seconds, 1e6 * busy / rows)}
 
 
+class Workload:
+    """One configured workload: device-resident synthetic input + the step that runs the hot path on it."""
+    pass
+
+
+def resolve_workload(name, batch_override=0):
+    if name in WORKLOADS:
+        wl = dict(WORKLOADS[name])
+    else:
+        import re
+        m = re.fullmatch(r"(cfft_f32|cfft_q15|cfft_q31|rfft_f32|rfft_q15|rfft_q31)_(\d+)x(\d+)", name)
+        if not m:
+            raise SystemExit("unknown workload %r" % name)
+        k = {"cfft_f32": "f32", "cfft_q15": "q15", "cfft_q31": "q31", "rfft_f32": "rfft", "rfft_q15": "rq15", "rfft_q31": "rq31"}[m.group(1)]
+        wl = dict(kind=k, n=int(m.group(2)), batch=int(m.group(3)), dtype={"rfft": "f32", "rq15": "q15", "rq31": "q31"}.get(k, k))
+        if k == "f32" and wl["n"] > 16384:
+            wl["kind"] = "large"
+    if batch_override:
+        wl["batch"] = batch_override
+    return wl
+
+
+def build_workload(name, wl, rank, stream, dop_range=None):
+    """Synthetic input resident in HBM + step().  dop_range: GNSS only, the [d0, d1) this rank searches."""
+    import numpy as np
+    import torch
+
+    import fft_amd
+    from fft_amd import lib
+
+    w = Workload()
+    w.name, w.kind, w.n, w.batch, w.dtype = name, wl["kind"], wl["n"], wl["batch"], wl["dtype"]
+    kind, n, batch = w.kind, w.n, w.batch
+    gen = torch.Generator(device="cuda").manual_seed(0x5EED0001 + rank)
+    vp = ctypes.c_void_p
+    w.rescale, w.chunk, w.out, w.extra_config = None, 1 << 30, None, {}
+    if kind == "f32":
+        S = fft_amd.arm_cfft_instance_f32()
+        assert lib.arm_cfft_init_f32(ctypes.byref(S), n) == 0
+        # The unnormalised forward transform grows the data by sqrt(N) RMS per pass (x64 at 4096), in
+        # place.  Start at 2^-100 and scale back by the exact power of two every `chunk` passes, chunk
+        # sized to 180 binades of growth (30 passes at 4096: the default warm-up + 20 passes need none, so
+        # the timed region holds the transforms only); the factor is applied in two halves because
+        # 2^-180 is not a float32.
+        growth = int(np.log2(n)) / 2.0
+        w.chunk = max(1, int(180 // growth))
+        data = ((torch.rand((batch, 2 * n), device="cuda", generator=gen) * 2 - 1) * 2.0 ** -100).contiguous()
+        w.step = lambda: lib.arm_cfft_f32_dev(ctypes.byref(S), vp(data.data_ptr()), batch, 0, 1, stream)
+        _half = 2.0 ** (-(growth * w.chunk) / 2.0)
+        w.rescale = lambda: data.mul_(_half).mul_(_half)
+        w.bytes_per_xform, w.flops_per_xform = 16 * n, 5.0 * n * np.log2(n)
+        w.kernel_name = "cfft_f32_kernel<%d, false>" % int(np.log2(n))
+        w.data = data
+    elif kind == "large":
+        S = fft_amd.arm_cfft_instance_u32_f32()
+        assert lib.arm_cfft_init_u32_f32(ctypes.byref(S), n) == 0
+        w.chunk = 4
+        data = ((torch.rand((batch, 2 * n), device="cuda", generator=gen) * 2 - 1) * 2.0 ** -48).contiguous()
+        work = torch.empty_like(data)
+        w.step = lambda: lib.arm_cfft_u32_f32_dev(ctypes.byref(S), vp(data.data_ptr()), vp(work.data_ptr()), batch, 0, stream)
+        w.rescale = lambda: data.mul_(2.0 ** (-(int(np.log2(n)) // 2) * w.chunk))
+        # algorithmic bytes per SURVEY 8(d): 16*N per transform; the four-step moves every point twice
+        w.bytes_per_xform, w.flops_per_xform = 16 * n, 5.0 * n * np.log2(n)
+        w.kernel_name = "fourstep_pass_kernel<%d|%d, 1|2, false> (two launches per step)" % ((int(np.log2(n)) + 1) // 2, int(np.log2(n)) // 2)
+        w.data, w.work = data, work
+    elif kind == "gnss":
+        n_ms, spc, spm = 10, 4, 4092
+        prns = np.arange(1, 33, dtype=np.int32)
+        dops = np.array([-5000.0 + 250.0 * k for k in range(41)], np.float32)
+        plan = vp()
+        assert lib.gnss_acq_plan_create(ctypes.byref(plan), n, spm, n_ms, spc, prns.ctypes.data_as(vp), len(prns),
+                                        dops.ctypes.data_as(vp), len(dops)) == 0, fft_amd.last_error()
+        # synthetic scenes on the device: six C/A signals (codes from the library's own getCode kernel)
+        # at fixed delays/Dopplers + white Gaussian noise, sigma 2.0 per component, a new draw per scene
+        # (seeded per scene set, NOT per rank, when the Doppler bins are sharded: every rank holds the same scenes)
+        if dop_range is not None:
+            gen = torch.Generator(device="cuda").manual_seed(0x5EED0006)
+        nn = n_ms * spm
+        tt = torch.arange(nn, device="cuda", dtype=torch.float64)
+        clean = torch.zeros((nn, 2), device="cuda", dtype=torch.float64)
+        code = torch.zeros(spm, dtype=torch.int32, device="cuda")
+        for prn, ph, fd in zip([3, 7, 11, 19, 22, 30], [100, 1033, 2047, 3000, 3555, 4000], [-4250.0, -1500.0, 0.0, 750.0, 2250.0, 4750.0]):
+            assert lib.gnss_get_code_dev(1023, spc, prn, vp(code.data_ptr())) == 0, fft_amd.last_error()
+            c = code.double()[(torch.arange(nn, device="cuda") - ph) % spm]
+            arg = 2 * np.pi * fd * tt / (1.023e6 * spc)
+            clean[:, 0] += c * torch.cos(arg)
+            clean[:, 1] += c * torch.sin(arg)
+        data = (clean.float()[None] + 2.0 * torch.randn((batch, nn, 2), device="cuda", generator=gen)).contiguous()
+        cells = torch.zeros((batch, len(prns), len(dops), 8), dtype=torch.int32, device="cuda")
+        best = torch.zeros((batch, len(prns), 8), dtype=torch.int32, device="cuda")
+        d0, d1 = dop_range if dop_range is not None else (0, len(dops))
+        w.acquire = lambda a, b: lib.gnss_acquire_dev(plan, vp(data.data_ptr()), batch, a, b, vp(cells.data_ptr()), vp(best.data_ptr()), stream)
+        w.step = lambda: w.acquire(d0, d1)
+        w.rows_per_scene = len(prns) * len(dops)
+        w.n_prn, w.n_dop, w.prns = len(prns), len(dops), prns
+        # "transform" = one scene; flops at 5NlogN per FFT: one forward per Doppler bin + one inverse per (PRN, bin)
+        w.flops_per_xform = (len(dops) + w.rows_per_scene) * 5.0 * n * np.log2(n)
+        w.bytes_per_xform = nn * 8 + w.rows_per_scene * 32                      # compulsory HBM bytes: signal in, tuples out
+        w.kernel_name = "gnss_acquire_kernel<12>"
+        w.data, w.cells, w.best, w.plan = data, cells, best, plan
+        w.extra_config = {"prns": 32, "doppler_bins": 41, "coherent_ms": 10, "scenes_per_gpu": batch}
+    elif kind in ("rq15", "rq31"):
+        q = kind[1:]
+        S = (fft_amd.arm_rfft_instance_q15 if q == "q15" else fft_amd.arm_rfft_instance_q31)()
+        assert getattr(lib, "arm_rfft_init_" + q)(ctypes.byref(S), n, 0, 1) == 0
+        dt, amp = (torch.int16, 16384) if q == "q15" else (torch.int32, 2 ** 30)
+        data = torch.randint(-amp, amp, (batch, n), device="cuda", generator=gen, dtype=dt)
+        out = torch.zeros((batch, 2 * n), device="cuda", dtype=dt)
+        fn = getattr(lib, "arm_rfft_%s_dev" % q)
+        w.step = lambda: fn(ctypes.byref(S), vp(data.data_ptr()), vp(out.data_ptr()), batch, stream)
+        sz = 2 if q == "q15" else 4
+        w.bytes_per_xform, w.flops_per_xform = 3 * n * sz, 2.5 * n * np.log2(n)      # n scalars in, 2n scalars out (spectrum + mirror)
+        w.kernel_name = "rfft_fixed_kernel<%s, %d, false>" % (q.upper(), int(np.log2(n)) - 1)
+        w.data, w.out = data, out
+    elif kind in ("q15", "q31"):
+        S = (fft_amd.arm_cfft_instance_q15 if kind == "q15" else fft_amd.arm_cfft_instance_q31)()
+        assert getattr(lib, "arm_cfft_init_" + kind)(ctypes.byref(S), n) == 0
+        dt, amp = (torch.int16, 16384) if kind == "q15" else (torch.int32, 2 ** 30)
+        data = torch.randint(-amp, amp, (batch, 2 * n), device="cuda", generator=gen, dtype=dt)
+        fn = getattr(lib, "arm_cfft_%s_dev" % kind)
+        w.step = lambda: fn(ctypes.byref(S), vp(data.data_ptr()), batch, 0, 1, stream)   # fixed point scales itself by 1/N per pass
+        w.bytes_per_xform, w.flops_per_xform = (8 if kind == "q15" else 16) * n, 5.0 * n * np.log2(n)
+        w.kernel_name = "cfft_fixed_kernel<%s, %d, false>" % (kind.upper(), int(np.log2(n)))
+        w.data = data
+    else:
+        S = fft_amd.arm_rfft_fast_instance_f32()
+        assert lib.arm_rfft_fast_init_f32(ctypes.byref(S), n) == 0
+        data = (torch.rand((batch, n), device="cuda", generator=gen) * 2 - 1).contiguous()
+        out = torch.empty_like(data)
+        w.step = lambda: lib.arm_rfft_fast_f32_dev(ctypes.byref(S), vp(data.data_ptr()), vp(out.data_ptr()), batch, 0, stream)
+        w.bytes_per_xform, w.flops_per_xform = 8 * n, 2.5 * n * np.log2(n)
+        w.kernel_name = "rfft_f32_kernel<%d, false>" % (int(np.log2(n)) - 1)
+        w.data, w.out = data, out
+    w.inst = S if kind != "gnss" else None   # keeps the ctypes instance alive as long as the step closure
+    return w
+
+
+def run_steps(w, m, timed, state, ev0, ev1):
+    """m passes of w.step(); timed: HIP events on the launch stream around the launches (the rescale that keeps
+    f32 data finite stays outside the events, inside the caller's wall clock)."""
+    import fft_amd
+    while m > 0:
+        todo = min(m, w.chunk - state["passes"] % w.chunk) if w.rescale else m
+        if timed:
+            ev0.record()
+        for _ in range(todo):
+            assert w.step() == 0, fft_amd.last_error()
+        if timed:
+            ev1.record()
+        state["passes"] += todo
+        m -= todo
+        if w.rescale and state["passes"] % w.chunk == 0:
+            w.rescale()
+        if timed:
+            ev1.synchronize()
+            state["kernel_ms"] += ev0.elapsed_time(ev1)
+
+
+def roofline_of(w, launch_s, traffic_table):
+    """The roofline object of one workload from its average launch time (seconds)."""
+    traffic = traffic_table.get(w.name)
+    src = "profiles/hbm_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes of this workload (not collected in this run)" if traffic is not None else None
+    if w.kind == "gnss":
+        # not HBM-bound (SURVEY 8d): priced against the fp32 vector peak, 157.3 TFLOP/s
+        tf = w.batch * w.flops_per_xform / launch_s / 1e12
+        return {"bound": "fp32-valu (LDS-resident FFTs; HBM traffic is only signal in + tuples out)", "achieved": round(tf, 2), "peak": 157.3,
+                "unit": "TFLOP/s", "frac": round(tf / 157.3, 4), "traffic": traffic, "traffic_source": src, "kernel": w.kernel_name,
+                "algorithmic_flops_per_launch": w.batch * w.flops_per_xform, "compulsory_hbm_bytes_per_launch": w.batch * w.bytes_per_xform,
+                "avg_launch_ms": round(1e3 * launch_s, 4)}
+    achieved = w.batch * w.bytes_per_xform / launch_s / 1e9
+    return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": traffic, "traffic_source": src, "kernel": w.kernel_name, "algorithmic_bytes_per_launch": w.batch * w.bytes_per_xform,
+            "avg_launch_ms": round(1e3 * launch_s, 4)}
+
+
+EXTRA_WORKLOADS = ["cfft_q15_4096x65536", "cfft_q31_4096x65536", "rfft_f32_16384x16384", "cfft_f32_4194304x8", "gnss_acq_gps_l1_x256"]
+
+
+def measure_extra(name, steps, stream, traffic_table):
+    """One of the other BASELINE configs, measured like the headline (HIP events on the launch stream, wall clock
+    around them), a few steps, memory released afterwards."""
+    import torch
+    wl = resolve_workload(name)
+    w = build_workload(name, wl, 0, stream)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    state = {"passes": 0, "kernel_ms": 0.0}
+    run_steps(w, 2, False, state, ev0, ev1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_steps(w, steps, True, state, ev0, ev1)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    launch_s = state["kernel_ms"] / 1e3 / steps
+    if w.kind == "gnss":
+        metric, value, unit = "GNSS acquisition cells/s (PRN x Doppler bin x code phase)", round(w.batch * steps * 32 * 41 * 4096 / elapsed, 1), "cells/s"
+    else:
+        metric, value, unit = name + " GFLOP/s (5NlogN; real: 2.5NlogN)", round(w.batch * steps * w.flops_per_xform / elapsed / 1e9, 2), "GFLOP/s"
+    out = {"workload": name, "metric": metric, "value": value, "unit": unit, "steps": steps, "warmup": 2, "ms_per_step": round(1e3 * elapsed / steps, 4),
+           "dtype": w.dtype, "roofline": roofline_of(w, launch_s, traffic_table)}
+    if w.kind == "gnss":
+        from fft_amd import lib
+        lib.gnss_acq_plan_destroy(w.plan)
+    del w
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     args = parse()
     import numpy as np
@@ -210,6 +499,7 @@ def main():
 
     import fft_amd
     from fft_amd import lib
+    from fft_amd import dist as D
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -221,118 +511,28 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert lib.arm_fft_mi355_set_device(local_rank) == 0, fft_amd.last_error()
 
-    if args.workload in WORKLOADS:
-        wl = dict(WORKLOADS[args.workload])
-    else:
-        import re
-        m = re.fullmatch(r"(cfft_f32|cfft_q15|cfft_q31|rfft_f32|rfft_q15|rfft_q31)_(\d+)x(\d+)", args.workload)
-        if not m:
-            raise SystemExit("unknown workload %r" % args.workload)
-        k = {"cfft_f32": "f32", "cfft_q15": "q15", "cfft_q31": "q31", "rfft_f32": "rfft", "rfft_q15": "rq15", "rfft_q31": "rq31"}[m.group(1)]
-        wl = dict(kind=k, n=int(m.group(2)), batch=int(m.group(3)), dtype={"rfft": "f32", "rq15": "q15", "rq31": "q31"}.get(k, k))
-        if k == "f32" and wl["n"] > 16384:
-            wl["kind"] = "large"
-    if args.batch:
-        wl["batch"] = args.batch
-    kind, n, batch = wl["kind"], wl["n"], wl["batch"]
+    wl = resolve_workload(args.workload, args.batch)
     K, W = args.steps, args.warmup
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    gen = torch.Generator(device="cuda").manual_seed(0x5EED0001 + rank)
+    shard_doppler = wl["kind"] == "gnss" and args.gnss_shard == "doppler"
+    w = build_workload(args.workload, wl, rank, stream, dop_range=D.doppler_range(41, rank, world) if shard_doppler else None)
+    kind, n, batch = w.kind, w.n, w.batch
+    merged = None
+    if shard_doppler:
+        # one step = this rank's Doppler bins of every scene + ONE all-gather of the winners (fft_amd.dist.sharded_acquire,
+        # the function tests/test_dist_cpu.py drives over gloo); the tuples live on the device the process group works on
+        rows = batch * w.n_prn
+        row_prns = torch.as_tensor(np.tile(w.prns, batch), dtype=torch.int32, device="cuda")
 
-    # ---- synthetic input, resident in HBM before the timed region ----
-    if kind == "f32":
-        S = fft_amd.arm_cfft_instance_f32()
-        assert lib.arm_cfft_init_f32(ctypes.byref(S), n) == 0
-        # The unnormalised forward transform grows the data by sqrt(N) RMS per pass (x64 at 4096), in
-        # place.  Start at 2^-100 and scale back by the exact power of two every `chunk` passes, chunk
-        # sized to 180 binades of growth (30 passes at 4096: the default 3 + 20 passes need none, so
-        # the timed region holds the transforms only); the factor is applied in two halves because
-        # 2^-180 is not a float32.
-        growth = int(np.log2(n)) / 2.0
-        chunk = max(1, int(180 // growth))
-        amp = 2.0 ** -100
-        data = ((torch.rand((batch, 2 * n), device="cuda", generator=gen) * 2 - 1) * amp).contiguous()
-        step = lambda: lib.arm_cfft_f32_dev(ctypes.byref(S), ctypes.c_void_p(data.data_ptr()), batch, 0, 1, stream)
-        _half = 2.0 ** (-(growth * chunk) / 2.0)
-        rescale = lambda: data.mul_(_half).mul_(_half)
-        bytes_per_xform, flops_per_xform = 16 * n, 5.0 * n * np.log2(n)
-        kernel_name = "cfft_f32_kernel<%d, false>" % int(np.log2(n))
-    elif kind == "large":
-        S = fft_amd.arm_cfft_instance_u32_f32()
-        assert lib.arm_cfft_init_u32_f32(ctypes.byref(S), n) == 0
-        chunk = 4
-        amp = 2.0 ** -48
-        data = ((torch.rand((batch, 2 * n), device="cuda", generator=gen) * 2 - 1) * amp).contiguous()
-        work = torch.empty_like(data)
-        step = lambda: lib.arm_cfft_u32_f32_dev(ctypes.byref(S), ctypes.c_void_p(data.data_ptr()), ctypes.c_void_p(work.data_ptr()),
-                                                batch, 0, stream)
-        rescale = lambda: data.mul_(2.0 ** (-(int(np.log2(n)) // 2) * chunk))
-        # algorithmic bytes per SURVEY 8(d): 16*N per transform; the four-step moves every point twice
-        bytes_per_xform, flops_per_xform = 16 * n, 5.0 * n * np.log2(n)
-        kernel_name = "fourstep_pass_kernel<%d|%d, 1|2, false> (two launches per step)" % ((int(np.log2(n)) + 1) // 2, int(np.log2(n)) // 2)
-    elif kind == "gnss":
-        n_ms, spc, spm = 10, 4, 4092
-        prns = np.arange(1, 33, dtype=np.int32)
-        dops = np.array([-5000.0 + 250.0 * k for k in range(41)], np.float32)
-        plan = ctypes.c_void_p()
-        assert lib.gnss_acq_plan_create(ctypes.byref(plan), n, spm, n_ms, spc, prns.ctypes.data_as(ctypes.c_void_p), len(prns),
-                                        dops.ctypes.data_as(ctypes.c_void_p), len(dops)) == 0, fft_amd.last_error()
-        # synthetic scenes on the device: six C/A signals (codes from the library's own getCode kernel)
-        # at fixed delays/Dopplers + white Gaussian noise, sigma 2.0 per component, a new draw per scene
-        nn = n_ms * spm
-        tt = torch.arange(nn, device="cuda", dtype=torch.float64)
-        clean = torch.zeros((nn, 2), device="cuda", dtype=torch.float64)
-        code = torch.zeros(spm, dtype=torch.int32, device="cuda")
-        for prn, ph, fd in zip([3, 7, 11, 19, 22, 30], [100, 1033, 2047, 3000, 3555, 4000], [-4250.0, -1500.0, 0.0, 750.0, 2250.0, 4750.0]):
-            assert lib.gnss_get_code_dev(1023, spc, prn, ctypes.c_void_p(code.data_ptr())) == 0, fft_amd.last_error()
-            c = code.double()[(torch.arange(nn, device="cuda") - ph) % spm]
-            arg = 2 * np.pi * fd * tt / (1.023e6 * spc)
-            clean[:, 0] += c * torch.cos(arg)
-            clean[:, 1] += c * torch.sin(arg)
-        data = (clean.float()[None] + 2.0 * torch.randn((batch, nn, 2), device="cuda", generator=gen)).contiguous()
-        cells = torch.zeros((batch, len(prns), len(dops), 8), dtype=torch.int32, device="cuda")
-        best = torch.zeros((batch, len(prns), 8), dtype=torch.int32, device="cuda")
-        step = lambda: lib.gnss_acquire_dev(plan, ctypes.c_void_p(data.data_ptr()), batch, 0, len(dops), ctypes.c_void_p(cells.data_ptr()),
-                                            ctypes.c_void_p(best.data_ptr()), stream)
-        rescale, chunk = None, 1 << 30
-        rows_per_scene = len(prns) * len(dops)
-        # "transform" = one scene; flops at 5NlogN per FFT: one forward per Doppler bin + one inverse per (PRN, bin)
-        flops_per_xform = (len(dops) + rows_per_scene) * 5.0 * n * np.log2(n)
-        bytes_per_xform = nn * 8 + rows_per_scene * 32                      # compulsory HBM bytes: signal in, tuples out
-        kernel_name = "gnss_acquire_kernel<12>"
-    elif kind in ("rq15", "rq31"):
-        q = kind[1:]
-        S = (fft_amd.arm_rfft_instance_q15 if q == "q15" else fft_amd.arm_rfft_instance_q31)()
-        assert getattr(lib, "arm_rfft_init_" + q)(ctypes.byref(S), n, 0, 1) == 0
-        dt, amp = (torch.int16, 16384) if q == "q15" else (torch.int32, 2 ** 30)
-        data = torch.randint(-amp, amp, (batch, n), device="cuda", generator=gen, dtype=dt)
-        out = torch.zeros((batch, 2 * n), device="cuda", dtype=dt)
-        fn = getattr(lib, "arm_rfft_%s_dev" % q)
-        step = lambda: fn(ctypes.byref(S), ctypes.c_void_p(data.data_ptr()), ctypes.c_void_p(out.data_ptr()), batch, stream)
-        rescale, chunk = None, 1 << 30
-        sz = 2 if q == "q15" else 4
-        bytes_per_xform, flops_per_xform = 3 * n * sz, 2.5 * n * np.log2(n)      # n scalars in, 2n scalars out (spectrum + mirror)
-        kernel_name = "rfft_fixed_kernel<%s, %d, false>" % (q.upper(), int(np.log2(n)) - 1)
-    elif kind in ("q15", "q31"):
-        I = fft_amd.arm_cfft_instance_q15 if kind == "q15" else fft_amd.arm_cfft_instance_q31
-        S = I()
-        assert getattr(lib, "arm_cfft_init_" + kind)(ctypes.byref(S), n) == 0
-        dt, amp = (torch.int16, 16384) if kind == "q15" else (torch.int32, 2 ** 30)
-        data = torch.randint(-amp, amp, (batch, 2 * n), device="cuda", generator=gen, dtype=dt)
-        fn = getattr(lib, "arm_cfft_%s_dev" % kind)
-        step = lambda: fn(ctypes.byref(S), ctypes.c_void_p(data.data_ptr()), batch, 0, 1, stream)
-        rescale, chunk = None, 1 << 30  # fixed point scales itself by 1/N per pass
-        bytes_per_xform, flops_per_xform = (8 if kind == "q15" else 16) * n, 5.0 * n * np.log2(n)
-        kernel_name = "cfft_fixed_kernel<%s, %d, false>" % (kind.upper(), int(np.log2(n)))
-    else:
-        S = fft_amd.arm_rfft_fast_instance_f32()
-        assert lib.arm_rfft_fast_init_f32(ctypes.byref(S), n) == 0
-        data = (torch.rand((batch, n), device="cuda", generator=gen) * 2 - 1).contiguous()
-        out = torch.empty_like(data)
-        step = lambda: lib.arm_rfft_fast_f32_dev(ctypes.byref(S), ctypes.c_void_p(data.data_ptr()), ctypes.c_void_p(out.data_ptr()), batch, 0, stream)
-        rescale, chunk = None, 1 << 30
-        bytes_per_xform, flops_per_xform = 8 * n, 2.5 * n * np.log2(n)
-        kernel_name = "rfft_f32_kernel<%d, false>" % (int(np.log2(n)) - 1)
+        def acquire(a, b):
+            assert w.acquire(a, b) == 0, fft_amd.last_error()
+            return w.best.view(rows, 8)
+
+        def step_sharded():
+            nonlocal merged
+            merged, _ = D.sharded_acquire(acquire, w.n_dop, rows, rank, world, row_prns=row_prns, device="cuda")
+            return 0
+        w.step = step_sharded
 
     def barrier():
         if world > 1:
@@ -342,28 +542,10 @@ def main():
     ev0 = torch.cuda.Event(enable_timing=True)
     ev1 = torch.cuda.Event(enable_timing=True)
     state = {"passes": 0, "kernel_ms": 0.0}
-
-    def do_steps(m, timed):
-        while m > 0:
-            todo = min(m, chunk - state["passes"] % chunk) if rescale else m
-            if timed:
-                ev0.record()
-            for _ in range(todo):
-                assert step() == 0, fft_amd.last_error()
-            if timed:
-                ev1.record()
-            state["passes"] += todo
-            m -= todo
-            if rescale and state["passes"] % chunk == 0:
-                rescale()  # keeps f32 data finite; inside the wall-clock region, outside the kernel events
-            if timed:
-                ev1.synchronize()
-                state["kernel_ms"] += ev0.elapsed_time(ev1)
-
-    do_steps(W, False)
+    run_steps(w, W, False, state, ev0, ev1)
     barrier()
     t0 = time.perf_counter()
-    do_steps(K, True)
+    run_steps(w, K, True, state, ev0, ev1)
     barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms = state["kernel_ms"]
@@ -375,22 +557,33 @@ def main():
 
     finite = True
     if kind in ("f32", "rfft", "large"):
-        finite = bool(torch.isfinite(out if kind == "rfft" else data).all())
+        finite = bool(torch.isfinite(w.out if kind == "rfft" else w.data).all())
+    merge_ok = None
+    if shard_doppler:
+        # outside the timed region: the merged tuples must equal this rank's own search of ALL bins
+        assert w.acquire(0, w.n_dop) == 0, fft_amd.last_error()
+        torch.cuda.synchronize()
+        merge_ok = bool(torch.equal(merged, w.best.view(batch * w.n_prn, 8)))
+        if world > 1:
+            f = torch.tensor([1.0 if merge_ok else 0.0], device="cuda")
+            dist.all_reduce(f, op=dist.ReduceOp.MIN)
+            merge_ok = bool(f.item() == 1.0)
+        assert merge_ok, "Doppler-sharded search + merge differs from the single-rank search of all bins"
 
     if rank == 0:
-        total_xforms = batch * K * world
-        gflops = total_xforms * flops_per_xform / elapsed / 1e9
-        launch_s = kernel_ms / 1e3 / K
-        achieved = batch * bytes_per_xform / launch_s / 1e9
-        traffic = None
+        traffic_table = {}
         tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tp):
             try:
-                traffic = json.load(open(tp)).get(args.workload)
+                traffic_table = json.load(open(tp))
             except Exception:
-                traffic = None
+                traffic_table = {}
+        scenes_total = batch * K * (1 if shard_doppler else world)
+        total_xforms = batch * K * world
+        gflops = total_xforms * w.flops_per_xform / elapsed / 1e9
+        launch_s = kernel_ms / 1e3 / K
         if kind == "gnss":
-            metric, value, unit = "GNSS acquisition cells/s (PRN x Doppler bin x code phase)", round(batch * K * world * 32 * 41 * 4096 / elapsed, 1), "cells/s"
+            metric, value, unit = "GNSS acquisition cells/s (PRN x Doppler bin x code phase)", round(scenes_total * 32 * 41 * 4096 / elapsed, 1), "cells/s"
         elif args.workload == "cfft_f32_4096x65536":
             metric, value, unit = "batched cfft_f32 4096-pt GFLOP/s (5NlogN) + % HBM roofline; GNSS acq cells/s", round(gflops, 2), "GFLOP/s"
         else:
@@ -404,29 +597,33 @@ def main():
             "warmup": W,
             "ms_per_step": round(1e3 * elapsed / K, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if shard_doppler else "weak",
             "vs_baseline": None,
-            "dtype": wl["dtype"],
+            "dtype": w.dtype,
             "data": "synthetic",
             "config": {"workload": args.workload, "fft_len": n, "batch_per_gpu": batch, "direction": "forward",
                        "in_place": kind != "rfft", "sharding": "independent batches per GPU, no collective",
                        "output_finite": finite},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": kernel_name,
-                         "algorithmic_bytes_per_launch": batch * bytes_per_xform,
-                         "avg_launch_ms": round(1e3 * launch_s, 4)},
         }
-        if kind == "gnss":
-            # not HBM-bound: priced against the fp32 vector peak, 157.3 TFLOP/s
-            tf = batch * flops_per_xform / launch_s / 1e12
-            line["roofline"] = {"bound": "fp32-valu (LDS-resident FFTs; HBM traffic is only signal in + tuples out)",
-                                "achieved": round(tf, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(tf / 157.3, 4),
-                                "traffic": traffic, "kernel": kernel_name, "algorithmic_flops_per_launch": batch * flops_per_xform,
-                                "compulsory_hbm_bytes_per_launch": batch * bytes_per_xform, "avg_launch_ms": round(1e3 * launch_s, 4)}
-            line["config"].update({"prns": 32, "doppler_bins": 41, "coherent_ms": 10, "scenes_per_gpu": batch,
-                                   "sharding": "scenes per GPU, no collective"})
+        if shard_doppler:
+            # the events bracket kernels AND the all-gather here: report the step time, not a kernel roofline of a partial search
+            line["roofline"] = roofline_of(w, launch_s, {})
+            line["roofline"]["note"] = "avg_launch_ms spans this rank's share of the Doppler bins plus the all-gather of the winners"
+            line["config"].update(w.extra_config)
+            line["config"].update({"sharding": "Doppler bins per GPU (41 bins over %d ranks), scenes replicated, one all-gather of %d x 32-byte tuples per step"
+                                               % (world, batch * w.n_prn), "merged_equals_single_rank_search": merge_ok})
+        else:
+            line["roofline"] = roofline_of(w, launch_s, traffic_table)
+            if kind == "gnss":
+                line["config"].update(w.extra_config)
+                line["config"]["sharding"] = "scenes per GPU, no collective"
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(kind, n, args.cpu_seconds)
+        if world == 1 and not args.no_extra and args.workload == "cfft_f32_4096x65536" and not args.batch:
+            # the other configs, measured in this same run (the headline's memory is released first)
+            del w
+            torch.cuda.empty_cache()
+            line["extra"] = [measure_extra(nm, args.extra_steps, stream, traffic_table) for nm in EXTRA_WORKLOADS]
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
