@@ -6,7 +6,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int
 
 __all__ = [
     "lib", "lib_path", "ARM_MATH_SUCCESS", "ARM_MATH_ARGUMENT_ERROR",
-    "arm_rfft_instance_q15", "arm_rfft_instance_q31", "gnss_acq_result", "gnss_top2", "bb_meas_t", "bb_meas_sat_t", "SYS_GPS", "SYS_GAL", "arm_cfft_radix2_instance_f32", "arm_cfft_instance_u32_f32", "arm_cfft_instance_f32", "arm_cfft_instance_q15", "arm_cfft_instance_q31", "arm_rfft_fast_instance_f32",
+    "arm_rfft_instance_q15", "arm_rfft_instance_q31", "gnss_acq_result", "gnss_top2", "top2_pks", "iq_resamp_zp_t", "bb_meas_t", "bb_meas_sat_t", "SYS_GPS", "SYS_GAL", "arm_cfft_radix2_instance_f32", "arm_cfft_instance_u32_f32", "arm_cfft_instance_f32", "arm_cfft_instance_q15", "arm_cfft_instance_q31", "arm_rfft_fast_instance_f32",
     "last_error", "EXPORTED_SYMBOLS",
 ]
 
@@ -77,6 +77,14 @@ class gnss_top2(Structure):
     _fields_ = [("val1", c_float), ("idx1", c_int32), ("val2", c_float), ("idx2", c_int32)]
 
 
+class top2_pks(Structure):            # Include/gnss_codes.h:42-47
+    _fields_ = [("idx1", ctypes.c_size_t), ("val1", c_float), ("idx2", ctypes.c_size_t), ("val2", c_float)]
+
+
+class iq_resamp_zp_t(Structure):      # Include/up_sample.h:11-18
+    _fields_ = [("fin", c_double), ("fout", c_double), ("dt", c_double), ("ntaps", c_int), ("half", c_int), ("cutoff", c_double)]
+
+
 class arm_rfft_fast_instance_f32(Structure):
     _fields_ = [("Sint", arm_cfft_instance_f32), ("fftLenRFFT", c_uint16), ("pTwiddleRFFT", POINTER(c_float))]
 
@@ -105,6 +113,9 @@ EXPORTED_SYMBOLS = (
     + ["arm_rfft_init_%d_%s" % (n, q) for n in (32, 64, 128, 256, 512, 1024, 2048, 4096, 8192) for q in ("q15", "q31")]
     + ["up_sample_N_to_M", "up_sample_10k_to_16k", "iq_resamp_zero_phase_dev", "iq_resamp_zero_phase_count"]
     + ["write_bb_msb", "read_bb_msb", "gnss_acq_to_meas", "gnss_acq_plan_create_replicas", "gnss_l5_generate_I_dev"]
+    + ["gnss_e1b_cboc_replica_dev", "gnss_hexstream_to_chips", "gnss_acquire_multi"]
+    + ["getCode", "synth_gps_prn", "find_top2_peaks_cplx", "find_top2_peaks_real", "compute_snr_cplx", "compute_snr_real", "InterpolateCodePhase"]
+    + ["iq_resamp_zp_init", "iq_resamp_process_zero_phase", "iq_resamp_zp_free"]
     + ["arm_fft_mi355_set_device", "arm_fft_mi355_warm", "arm_fft_mi355_last_error",
        "arm_fft_mi355_set_twiddle_rounding", "arm_fft_mi355_version"]
 )
@@ -200,6 +211,22 @@ def _load():
     L.gnss_acq_plan_create_replicas.argtypes = [POINTER(c_void_p), u32, u32, u32, c_void_p, c_void_p, u32, c_void_p, u32]
     L.gnss_acq_plan_create_replicas.restype = c_int
     L.gnss_l5_generate_I_dev.argtypes, L.gnss_l5_generate_I_dev.restype = [i32, u32, c_void_p], c_int
+    L.gnss_e1b_cboc_replica_dev.argtypes, L.gnss_e1b_cboc_replica_dev.restype = [c_void_p, u32, c_float, u32, c_void_p, c_void_p], c_int
+    L.gnss_hexstream_to_chips.argtypes, L.gnss_hexstream_to_chips.restype = [c_char_p, c_void_p, i32], c_int
+    L.gnss_acquire_multi.argtypes, L.gnss_acquire_multi.restype = [POINTER(c_void_p), u32, c_void_p, u32, c_void_p], c_int
+    sz = ctypes.c_size_t
+    L.getCode.argtypes, L.getCode.restype = [c_int, c_int, c_int, c_void_p], None
+    L.synth_gps_prn.argtypes, L.synth_gps_prn.restype = [c_int, c_float, sz, c_void_p, c_int], None
+    for nm in ("find_top2_peaks_cplx", "find_top2_peaks_real"):
+        f = getattr(L, nm)
+        f.argtypes, f.restype = [c_void_p, c_int, c_int, POINTER(top2_pks), c_void_p], c_int
+    for nm in ("compute_snr_cplx", "compute_snr_real"):
+        f = getattr(L, nm)
+        f.argtypes, f.restype = [c_void_p, c_int, dbl, c_int], dbl
+    L.InterpolateCodePhase.argtypes, L.InterpolateCodePhase.restype = [u32, dbl, dbl, dbl], dbl
+    L.iq_resamp_zp_init.argtypes, L.iq_resamp_zp_init.restype = [dbl, dbl, c_int, dbl], POINTER(iq_resamp_zp_t)
+    L.iq_resamp_process_zero_phase.argtypes, L.iq_resamp_process_zero_phase.restype = [POINTER(iq_resamp_zp_t), c_void_p, sz, c_void_p, sz], sz
+    L.iq_resamp_zp_free.argtypes, L.iq_resamp_zp_free.restype = [POINTER(iq_resamp_zp_t)], None
     L.arm_fft_mi355_set_device.argtypes, L.arm_fft_mi355_set_device.restype = [c_int], c_int
     L.arm_fft_mi355_warm.argtypes, L.arm_fft_mi355_warm.restype = [c_int, u32], c_int
     L.arm_fft_mi355_last_error.argtypes, L.arm_fft_mi355_last_error.restype = [], c_char_p

@@ -19,8 +19,16 @@
 // find_top2_peaks_cplx (gnss_codes.c:1144-1166) is a sequential scan whose second peak depends on
 // which index was the running best when each sample was seen; top2_scan() below reproduces it
 // exactly (values and indices, ties included) with a workgroup prefix scan.
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
 #include <atomic>
+#include <algorithm>
 #include <mutex>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "armfft_internal.h"
@@ -114,6 +122,49 @@ __global__ void gnss_l5_code_kernel(int prn, uint32_t n_chips, int8_t *__restric
       const unsigned a = t1 ? (g2_state[i] >> (t1 - 1u)) & 1u : 0u, b = t2 ? (g2_state[i] >> (t2 - 1u)) & 1u : 0u;
       out[base + i] = (g1_out[i] ^ a ^ b) ? -1 : 1;
     }
+  }
+}
+
+// synth_e1b_prn (gnss_codes.c:920-965) with cboc_e1b_weight (:253-260), boc_sign (:247-251) and code_chip_at
+// (:265-270): Galileo E1-B CBOC(6,1,1/11) replica at fs = 4.092 MHz, chip rate 1.023 MHz, code and carrier phase
+// starting at 0, data bit +1.  The reference advances BOTH phases by float recursion:
+//   chips += 1.023e6f / 4.092e6f (= 0.25 exactly; every sum and the wrap at 4092 are exact in f32), so
+//           chips(n) = (n mod 16368) / 4 in closed form;
+//   phia  += dphia, rounded to f32 at every step -- order-dependent, so ONE thread walks the n steps (a 16384-step
+//           dependent chain of f32 adds is ~60 us, once per plan) and leaves phia(n) in the output buffer's .x slot;
+// then every thread forms its sample: amplitude chip * (w1 * s11 - w6 * s61) in f32, carrier (float)cos / (float)sin of
+// the DOUBLE-evaluated f32 phase (sincosf_fast, :573-576).  One workgroup per code; codes = n_codes x 4092 chips (+1/-1,
+// the E1B_Code[prn] rows a caller loads from the ICD's hex tables: hexstream_to_e1b_chips :276-289).
+__global__ __launch_bounds__(256) void gnss_e1b_replica_kernel(const int8_t *__restrict__ codes, float doppler, uint32_t size, float2 *__restrict__ out)
+{
+  constexpr int L = 4092;
+  const int8_t *ca = codes + (size_t)blockIdx.x * L;
+  float2 *o = out + (size_t)blockIdx.x * size;
+  const float PI_F = 3.14159265358979f;  // Include/gnss_codes.h:33
+  const float fs_hz = 4.092e6f;
+  if (threadIdx.x == 0) {
+    const float dphia = 2.0f * PI_F * doppler / fs_hz;
+    float phia = 0.0f;
+    for (uint32_t n = 0; n < size; n++) {
+      o[n].x = phia;
+      phia = __fadd_rn(phia, dphia);
+      if (phia > 1e9f || phia < -1e9f) phia = fmodf(phia, 2.0f * PI_F);
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  const float w1 = 0.9534625892455923f, w6 = 0.3015113445777636f;
+  for (uint32_t n = threadIdx.x; n < size; n += blockDim.x) {
+    const uint32_t q = n % (4u * L);              // chips = q / 4, exact
+    const int idx = (int)(q >> 2);
+    const float frac = (float)(q & 3u) * 0.25f;
+    const int s11 = ((int)floorf(2.0f * 1 * frac) & 1) ? -1 : +1;
+    const int s61 = ((int)floorf(2.0f * 6 * frac) & 1) ? -1 : +1;
+    const float sca = __fsub_rn(__fmul_rn(w1, (float)s11), __fmul_rn(w6, (float)s61));
+    const float ampa = __fmul_rn((float)ca[idx], sca);
+    const double ph = (double)o[n].x;
+    const float sa = (float)sin(ph), caph = (float)cos(ph);
+    o[n] = make_float2(__fmul_rn(ampa, caph), __fmul_rn(ampa, sa));
   }
 }
 
@@ -371,6 +422,37 @@ __global__ __launch_bounds__(256) void gnss_top2_kernel(const float *__restrict_
     r.val2 = t.v2;
     r.idx2 = t.i2;
     out[blockIdx.x] = r;
+  }
+}
+
+// probe: compute_snr_cplx / compute_snr_real (gnss_codes.c:1110-1142): 10 log10(peak / mean of the magnitudes more than
+// two samples away from peak_loc), the mean over cov_size - 5 as in the reference; double sums (the reference adds the
+// float magnitudes into a double one by one; here per-thread partial sums in double, combined through LDS)
+template <bool CPLX>
+__global__ __launch_bounds__(256) void gnss_snr_kernel(const float *__restrict__ data, int n, double peak, int peak_loc, double *__restrict__ out)
+{
+  __shared__ double part[256];
+  double sum = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    float magn;
+    if (CPLX) {
+      const float re = data[2 * i], im = data[2 * i + 1];
+      magn = sqrtf(re * re + im * im);
+    } else {
+      magn = data[i];
+    }
+    const int d = i - peak_loc;
+    if ((d < 0 ? -d : d) > 2) sum += (double)magn;
+  }
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double mean = part[0] / (double)(n - 5);
+    out[0] = 10.0 * log10(peak / mean);
   }
 }
 
@@ -889,6 +971,21 @@ arm_status gnss_decode_ors_iq_dev(const uint8_t *data_dev, uint32_t byte_length,
   return hip_ok(hipGetLastError(), "gnss_decode_ors_kernel launch") ? ARM_MATH_SUCCESS : ARM_MATH_ARGUMENT_ERROR;
 }
 
+// staging of the host-pointer entry points (caller holds pl->mu, the plan's device is current)
+static bool ensure_stage(gnss_acq_plan *pl, uint32_t n_scenes)
+{
+  if (pl->stage_scenes >= n_scenes) return true;
+  const size_t sig_elems = (size_t)n_scenes * pl->n_ms * pl->spm, rows = (size_t)n_scenes * pl->n_prn;
+  (void)hipFree(pl->sig_stage); (void)hipFree(pl->all_stage); (void)hipFree(pl->best_stage);
+  pl->sig_stage = nullptr; pl->all_stage = nullptr; pl->best_stage = nullptr; pl->stage_scenes = 0;
+  if (!hip_ok(hipMalloc((void **)&pl->sig_stage, sizeof(float2) * sig_elems), "hipMalloc(signal staging)") ||
+      !hip_ok(hipMalloc((void **)&pl->all_stage, sizeof(gnss_acq_result) * rows * pl->n_dop), "hipMalloc(cell staging)") ||
+      !hip_ok(hipMalloc((void **)&pl->best_stage, sizeof(gnss_acq_result) * rows), "hipMalloc(result staging)"))
+    return false;
+  pl->stage_scenes = n_scenes;
+  return true;
+}
+
 arm_status gnss_acquire(gnss_acq_plan *pl, const float *signal, uint32_t n_scenes, gnss_acq_result *best, gnss_acq_result *all)
 {
   if (!pl || !signal || !best) { set_error("gnss_acquire: null argument"); return ARM_MATH_ARGUMENT_ERROR; }
@@ -896,15 +993,7 @@ arm_status gnss_acquire(gnss_acq_plan *pl, const float *signal, uint32_t n_scene
   if (!plan_on_device(pl, "gnss_acquire")) return ARM_MATH_ARGUMENT_ERROR;
   std::lock_guard<std::mutex> lk(pl->mu);
   const size_t sig_elems = (size_t)n_scenes * pl->n_ms * pl->spm, rows = (size_t)n_scenes * pl->n_prn;
-  if (pl->stage_scenes < n_scenes) {
-    (void)hipFree(pl->sig_stage); (void)hipFree(pl->all_stage); (void)hipFree(pl->best_stage);
-    pl->sig_stage = nullptr; pl->all_stage = nullptr; pl->best_stage = nullptr; pl->stage_scenes = 0;
-    if (!hip_ok(hipMalloc((void **)&pl->sig_stage, sizeof(float2) * sig_elems), "hipMalloc(signal staging)") ||
-        !hip_ok(hipMalloc((void **)&pl->all_stage, sizeof(gnss_acq_result) * rows * pl->n_dop), "hipMalloc(cell staging)") ||
-        !hip_ok(hipMalloc((void **)&pl->best_stage, sizeof(gnss_acq_result) * rows), "hipMalloc(result staging)"))
-      return ARM_MATH_ARGUMENT_ERROR;
-    pl->stage_scenes = n_scenes;
-  }
+  if (!ensure_stage(pl, n_scenes)) return ARM_MATH_ARGUMENT_ERROR;
   if (!hip_ok(hipMemcpy(pl->sig_stage, signal, sizeof(float2) * sig_elems, hipMemcpyHostToDevice), "hipMemcpy(H2D)")) return ARM_MATH_ARGUMENT_ERROR;
   arm_status st = gnss_acquire_dev(pl, reinterpret_cast<const float *>(pl->sig_stage), n_scenes, 0, (uint32_t)pl->n_dop, pl->all_stage,
                                    pl->best_stage, nullptr);
@@ -912,6 +1001,73 @@ arm_status gnss_acquire(gnss_acq_plan *pl, const float *signal, uint32_t n_scene
   if (!hip_ok(hipMemcpy(best, pl->best_stage, sizeof(gnss_acq_result) * rows, hipMemcpyDeviceToHost), "hipMemcpy(D2H)")) return ARM_MATH_ARGUMENT_ERROR;
   if (all && !hip_ok(hipMemcpy(all, pl->all_stage, sizeof(gnss_acq_result) * rows * pl->n_dop, hipMemcpyDeviceToHost), "hipMemcpy(D2H)"))
     return ARM_MATH_ARGUMENT_ERROR;
+  return ARM_MATH_SUCCESS;
+}
+
+// Multi-GPU search without Python or RCCL: the C caller of the reference's read_ors loop (CMSIS/CMSIS.cpp:706-737) hands over
+// one plan per GPU (each created with that GPU current; identical geometry, PRN list and Doppler grid).  Plan i searches the
+// i-th contiguous share of the Doppler bins on ITS device from its own host thread (hipSetDevice is per thread); the signal
+// is replicated to every device (327 KB per scene), nothing crosses between GPUs; the per-(scene, PRN) winners come back to
+// the host and are merged by the rule of gnss_best_kernel -- largest peak, lowest Doppler bin on ties -- which makes the
+// result identical to gnss_acquire on one plan.  Several plans may live on one device (they then share it).
+arm_status gnss_acquire_multi(gnss_acq_plan *const *plans, uint32_t n_plans, const float *signal, uint32_t n_scenes, gnss_acq_result *best)
+{
+  const char *who = "gnss_acquire_multi";
+  if (!plans || n_plans == 0 || !signal || !best) { set_error("%s: null argument", who); return ARM_MATH_ARGUMENT_ERROR; }
+  if (n_plans > 64) { set_error("%s: at most 64 plans", who); return ARM_MATH_ARGUMENT_ERROR; }
+  for (uint32_t i = 0; i < n_plans; i++) {
+    const gnss_acq_plan *a = plans[0], *b = plans[i];
+    if (!b) { set_error("%s: plan %u is null", who, i); return ARM_MATH_ARGUMENT_ERROR; }
+    for (uint32_t j = 0; j < i; j++)
+      if (plans[j] == b) { set_error("%s: plan %u is listed twice", who, i); return ARM_MATH_ARGUMENT_ERROR; }
+    if (b->fft_len != a->fft_len || b->spm != a->spm || b->n_ms != a->n_ms || b->n_prn != a->n_prn || b->n_dop != a->n_dop || b->pk_sep != a->pk_sep) {
+      set_error("%s: plan %u differs in geometry from plan 0", who, i);
+      return ARM_MATH_ARGUMENT_ERROR;
+    }
+  }
+  if (n_scenes == 0) return ARM_MATH_SUCCESS;
+  if (n_scenes > 65535) { set_error("%s: at most 65535 scenes per call", who); return ARM_MATH_ARGUMENT_ERROR; }
+  const int n_dop = plans[0]->n_dop;
+  const size_t rows = (size_t)n_scenes * plans[0]->n_prn, sig_elems = (size_t)n_scenes * plans[0]->n_ms * plans[0]->spm;
+  int prev_dev = 0;
+  (void)hipGetDevice(&prev_dev);
+  std::vector<std::vector<gnss_acq_result>> part(n_plans);
+  std::vector<std::string> errs(n_plans);
+  std::vector<std::thread> th;
+  for (uint32_t i = 0; i < n_plans; i++) {
+    // contiguous shares, the first n_dop % n_plans plans take one bin more (fft_amd/dist.py: doppler_range)
+    const int q = n_dop / (int)n_plans, r = n_dop % (int)n_plans;
+    const int d0 = (int)i * q + std::min((int)i, r), d1 = d0 + q + ((int)i < r ? 1 : 0);
+    if (d1 <= d0) continue;  // more plans than bins: this one has nothing to search
+    th.emplace_back([&, i, d0, d1] {
+      gnss_acq_plan *pl = plans[i];
+      bool ok = hip_ok(hipSetDevice(pl->device), "hipSetDevice");
+      if (ok) {
+        std::lock_guard<std::mutex> lk(pl->mu);
+        ok = ensure_stage(pl, n_scenes) &&
+             hip_ok(hipMemcpy(pl->sig_stage, signal, sizeof(float2) * sig_elems, hipMemcpyHostToDevice), "hipMemcpy(H2D)") &&
+             gnss_acquire_dev(pl, reinterpret_cast<const float *>(pl->sig_stage), n_scenes, (uint32_t)d0, (uint32_t)d1, pl->all_stage, pl->best_stage,
+                              nullptr) == ARM_MATH_SUCCESS;
+        if (ok) {
+          part[i].resize(rows);
+          ok = hip_ok(hipMemcpy(part[i].data(), pl->best_stage, sizeof(gnss_acq_result) * rows, hipMemcpyDeviceToHost), "hipMemcpy(D2H)");
+        }
+      }
+      if (!ok) errs[i] = arm_fft_mi355_last_error();  // thread-local message, handed to the calling thread below
+    });
+  }
+  for (auto &t : th) t.join();
+  (void)hipSetDevice(prev_dev);
+  for (uint32_t i = 0; i < n_plans; i++)
+    if (!errs[i].empty()) { set_error("%s: plan %u (device %d): %s", who, i, plans[i]->device, errs[i].c_str()); return ARM_MATH_ARGUMENT_ERROR; }
+  // merge: plans are in increasing bin order, so "strictly larger takes over" keeps the lowest bin on ties
+  bool first = true;
+  for (uint32_t i = 0; i < n_plans; i++) {
+    if (part[i].empty()) continue;
+    if (first) { memcpy(best, part[i].data(), sizeof(gnss_acq_result) * rows); first = false; continue; }
+    for (size_t k = 0; k < rows; k++)
+      if (part[i][k].peak > best[k].peak) best[k] = part[i][k];
+  }
   return ARM_MATH_SUCCESS;
 }
 
@@ -953,6 +1109,33 @@ arm_status gnss_l5_generate_I_dev(int32_t prn, uint32_t n_chips, int8_t *out_dev
   gnss_l5_code_kernel<<<1, 256, 0, nullptr>>>(prn, n_chips, out_dev);
   return hip_ok(hipGetLastError(), "gnss_l5_code_kernel") && hip_ok(hipStreamSynchronize(nullptr), "synchronise") ? ARM_MATH_SUCCESS
                                                                                                                  : ARM_MATH_ARGUMENT_ERROR;
+}
+
+arm_status gnss_e1b_cboc_replica_dev(const int8_t *codes_dev, uint32_t n_codes, float doppler, uint32_t size, float *replica_dev, void *stream)
+{
+  if (!codes_dev || !replica_dev) { set_error("gnss_e1b_cboc_replica_dev: null argument"); return ARM_MATH_ARGUMENT_ERROR; }
+  if (n_codes > 65535) { set_error("gnss_e1b_cboc_replica_dev: at most 65535 codes per call"); return ARM_MATH_ARGUMENT_ERROR; }
+  if (n_codes == 0 || size == 0) return ARM_MATH_SUCCESS;
+  gnss_e1b_replica_kernel<<<n_codes, 256, 0, (hipStream_t)stream>>>(codes_dev, doppler, size, reinterpret_cast<float2 *>(replica_dev));
+  return hip_ok(hipGetLastError(), "gnss_e1b_replica_kernel launch") ? ARM_MATH_SUCCESS : ARM_MATH_ARGUMENT_ERROR;
+}
+
+// hex_nibble + hexstream_to_e1b_chips / _e5a_chips / _e5a_qp_chips (gnss_codes.c:234-239, :276-325; they differ only in
+// the code length): host-side text work on a few KiB, nothing for a GPU to do
+int gnss_hexstream_to_chips(const char *hex_stream, int8_t *chips, int32_t code_len)
+{
+  if (!hex_stream || !chips || code_len <= 0) { set_error("gnss_hexstream_to_chips: bad argument"); return -1; }
+  int32_t chip_idx = 0;
+  for (const char *p = hex_stream; *p && chip_idx < code_len; ++p) {
+    const int c = (unsigned char)*p;
+    int v;
+    if (c >= '0' && c <= '9') v = c - '0';
+    else if (c >= 'A' && c <= 'F') v = 10 + (c - 'A');
+    else if (c >= 'a' && c <= 'f') v = 10 + (c - 'a');
+    else continue;  // separators are skipped
+    for (int b = 3; b >= 0 && chip_idx < code_len; --b) chips[chip_idx++] = ((v >> b) & 1) ? (int8_t)-1 : (int8_t)+1;  // logic 1 -> -1 (:243-245)
+  }
+  return chip_idx == code_len ? 0 : -1;
 }
 
 arm_status gnss_acq_plan_create_replicas(gnss_acq_plan **out, uint32_t fft_len, uint32_t samples_per_ms, uint32_t n_ms,
@@ -1031,6 +1214,108 @@ arm_status gnss_find_top2_peaks_dev(const float *data_dev, int32_t is_complex, i
   else
     gnss_top2_kernel<false><<<batch, 256, 0, (hipStream_t)stream>>>(data_dev, data_size, pk_sep, peaks_dev);
   return hip_ok(hipGetLastError(), "gnss_top2_kernel launch") ? ARM_MATH_SUCCESS : ARM_MATH_ARGUMENT_ERROR;
+}
+
+// ------------------------------------------------------------------------------------------
+// the reference's own names (Include/gnss_codes.h:62-126), host pointers: stage, run the device probes above, copy
+// back.  Void / value-returning entry points have no status channel: like arm_cfft_f32 they abort() with a message
+// when the GPU cannot run them (find_top2_peaks_* return -1 instead, as their reference signature allows).
+// ------------------------------------------------------------------------------------------
+namespace {
+struct DevBuf {
+  void *p = nullptr;
+  explicit DevBuf(size_t bytes) { if (bytes && !hip_ok(hipMalloc(&p, bytes), "hipMalloc(staging)")) p = nullptr; }
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+};
+[[noreturn]] void die(const char *who)
+{
+  fprintf(stderr, "libarmfft_mi355: %s cannot run (%s)\n", who, arm_fft_mi355_last_error());
+  abort();
+}
+}  // namespace
+
+// gnss_codes.c:969-1030
+void getCode(int num, int samplesPerChip, const int prn, int *out)
+{
+  if (!out || num <= 0) return;
+  if (samplesPerChip < 1) samplesPerChip = 1;  // :1010
+  const size_t total = (size_t)num * (size_t)samplesPerChip;
+  DevBuf d(total * sizeof(int32_t));
+  if (!d.p || gnss_get_code_dev(num, samplesPerChip, prn, (int32_t *)d.p) != ARM_MATH_SUCCESS ||
+      !hip_ok(hipMemcpy(out, d.p, total * sizeof(int32_t), hipMemcpyDeviceToHost), "hipMemcpy(D2H)"))
+    die("getCode");
+}
+
+// gnss_codes.c:1066-1071 (getCode + mix_prn :1032-1063)
+void synth_gps_prn(int prn, float doppler, size_t size, float32_t *replica, int spc)
+{
+  if (!replica || size == 0) return;
+  DevBuf d(size * sizeof(float2));
+  if (!d.p || size > 0xFFFFFFFFull || gnss_synth_gps_prn_dev(prn, doppler, (uint32_t)size, (float *)d.p, spc) != ARM_MATH_SUCCESS ||
+      !hip_ok(hipMemcpy(replica, d.p, size * sizeof(float2), hipMemcpyDeviceToHost), "hipMemcpy(D2H)"))
+    die("synth_gps_prn");
+}
+
+static int top2_host(const float *data, int is_complex, int data_size, int pk_sep, top2_pks *peaks, FILE *fp_out)
+{
+  if (data_size <= 0 || !data || !peaks) return -1;  // :1145 / :1169
+  if (fp_out) {  // the reference's debug dump of every magnitude (:1151, :1175): formatting only
+    for (int m = 0; m < data_size; m++) {
+      const float magn = is_complex ? sqrtf(data[2 * m] * data[2 * m] + data[2 * m + 1] * data[2 * m + 1]) : data[m];
+      fprintf(fp_out, "%d, %f \n", m, magn);
+    }
+  }
+  const size_t bytes = (size_t)data_size * (is_complex ? 2 : 1) * sizeof(float);
+  DevBuf d(bytes), r(sizeof(gnss_top2));
+  gnss_top2 t;
+  if (!d.p || !r.p || !hip_ok(hipMemcpy(d.p, data, bytes, hipMemcpyHostToDevice), "hipMemcpy(H2D)") ||
+      gnss_find_top2_peaks_dev((const float *)d.p, is_complex, data_size, pk_sep, 1, (gnss_top2 *)r.p, nullptr) != ARM_MATH_SUCCESS ||
+      !hip_ok(hipMemcpy(&t, r.p, sizeof t, hipMemcpyDeviceToHost), "hipMemcpy(D2H)"))
+    return -1;
+  peaks->val1 = t.val1;
+  peaks->idx1 = (size_t)t.idx1;  // -1 ("none") converts as in the reference's int -> size_t assignment (:1162-1165)
+  peaks->val2 = t.val2;
+  peaks->idx2 = (size_t)t.idx2;
+  return 0;
+}
+// gnss_codes.c:1144-1166 / :1168-1190; data_size <= 16384 here
+int find_top2_peaks_cplx(const float32_t *data, int data_size, int pk_sep, top2_pks *peaks, FILE *fp_out) { return top2_host(data, 1, data_size, pk_sep, peaks, fp_out); }
+int find_top2_peaks_real(const float32_t *data, int data_size, int pk_sep, top2_pks *peaks, FILE *fp_out) { return top2_host(data, 0, data_size, pk_sep, peaks, fp_out); }
+
+static double snr_host(const float *convol, int is_complex, int cov_size, double peak, int peak_loc, const char *who)
+{
+  if (!convol || cov_size <= 0) { set_error("%s: bad argument", who); die(who); }
+  const size_t bytes = (size_t)cov_size * (is_complex ? 2 : 1) * sizeof(float);
+  DevBuf d(bytes), r(sizeof(double));
+  double snr = 0.0;
+  bool ok = d.p && r.p && hip_ok(hipMemcpy(d.p, convol, bytes, hipMemcpyHostToDevice), "hipMemcpy(H2D)");
+  if (ok) {
+    if (is_complex) gnss_snr_kernel<true><<<1, 256, 0, nullptr>>>((const float *)d.p, cov_size, peak, peak_loc, (double *)r.p);
+    else gnss_snr_kernel<false><<<1, 256, 0, nullptr>>>((const float *)d.p, cov_size, peak, peak_loc, (double *)r.p);
+    ok = hip_ok(hipGetLastError(), "gnss_snr_kernel") && hip_ok(hipMemcpy(&snr, r.p, sizeof snr, hipMemcpyDeviceToHost), "hipMemcpy(D2H)");
+  }
+  if (!ok) die(who);
+  return snr;
+}
+// gnss_codes.c:1110-1125 / :1127-1142
+double compute_snr_cplx(float32_t *convol, int cov_size, double peak, int peak_loc) { return snr_host(convol, 1, cov_size, peak, peak_loc, "compute_snr_cplx"); }
+double compute_snr_real(float32_t *convol, int cov_size, double peak, int peak_loc) { return snr_host(convol, 0, cov_size, peak, peak_loc, "compute_snr_real"); }
+
+// gnss_codes.c:1096-1108: six floating-point operations on three doubles the caller already holds -- scalar host
+// arithmetic, there is no data to send to a GPU (the fused kernel evaluates the same formula per row, finish_row)
+double InterpolateCodePhase(uint32_t index, double earlyPower, double promptPower, double latePower)
+{
+  double interpolatedIndex;
+  if (latePower > earlyPower) {
+    interpolatedIndex = 0.5 * (latePower - earlyPower) / (promptPower - earlyPower);
+    interpolatedIndex = index + (interpolatedIndex / 3.0) * (2.0 * interpolatedIndex + 2.0);
+  } else {
+    interpolatedIndex = 0.5 * (latePower - earlyPower) / (promptPower - latePower);
+    interpolatedIndex = index + (interpolatedIndex / 3.0) * (-2.0 * interpolatedIndex + 2.0);
+  }
+  return interpolatedIndex;
 }
 
 }  // extern "C"

@@ -141,15 +141,16 @@ arm_status iq_resamp_zero_phase_dev(double fin_hz, double fout_hz, int32_t ntaps
 }
 
 // host pointers: one block, copies in and out; returns the number of samples written (0 on failure)
-static uint32_t resamp_host(double fin, double fout, const float *in, uint32_t n_in, float *out, uint32_t cap, const char *who)
+static uint32_t resamp_host(double fin, double fout, const float *in, uint32_t n_in, float *out, uint32_t cap, const char *who, int ntaps = 12,
+                            double cutoff = 0.45)
 {
-  const uint32_t n = iq_resamp_zero_phase_count(fin, fout, 12, 0.45, n_in, cap);
+  const uint32_t n = iq_resamp_zero_phase_count(fin, fout, ntaps, cutoff, n_in, cap);
   if (!in || !out || n == 0) return 0;
   float *din = nullptr, *dout = nullptr;
   bool ok = hip_ok(hipMalloc((void **)&din, sizeof(float) * 2 * n_in), "hipMalloc") && hip_ok(hipMalloc((void **)&dout, sizeof(float) * 2 * n), "hipMalloc");
   ok = ok && hip_ok(hipMemcpy(din, in, sizeof(float) * 2 * n_in, hipMemcpyHostToDevice), "hipMemcpy(H2D)");
   uint32_t got = 0;
-  ok = ok && iq_resamp_zero_phase_dev(fin, fout, 12, 0.45, din, n_in, dout, n, 1, &got, nullptr) == ARM_MATH_SUCCESS;
+  ok = ok && iq_resamp_zero_phase_dev(fin, fout, ntaps, cutoff, din, n_in, dout, n, 1, &got, nullptr) == ARM_MATH_SUCCESS;
   ok = ok && hip_ok(hipMemcpy(out, dout, sizeof(float) * 2 * n, hipMemcpyDeviceToHost), "hipMemcpy(D2H)");
   (void)hipFree(din);
   (void)hipFree(dout);
@@ -173,6 +174,34 @@ void up_sample_N_to_M(float32_t *in, int N_in, float32_t *out, int M_out)
 void up_sample_10k_to_16k(float32_t *in, float32_t *out)
 {
   (void)resamp_host(10230e3, 16384e3, in, 10230, out, (uint32_t)(llround(10230 * (16384e3 / 10230e3)) + 8), "up_sample_10k_to_16k");
+}
+
+// Include/up_sample.h:20-24, bodies up_sample.c:31-48 (init / free) and :115-157 (process): the reference's own
+// state object and calls, host pointers; the resampling itself runs on the GPU (one block per call).
+iq_resamp_zp_t *iq_resamp_zp_init(double fin_hz, double fout_hz, int ntaps, double cutoff)
+{
+  if (ntaps < 4 || (ntaps & 1)) return nullptr;             // up_sample.c:32
+  if (!(cutoff > 0.0 && cutoff <= 0.5)) return nullptr;     // :33
+  iq_resamp_zp_t *st = (iq_resamp_zp_t *)calloc(1, sizeof(iq_resamp_zp_t));
+  if (!st) return nullptr;
+  st->fin = fin_hz;
+  st->fout = fout_hz;
+  st->dt = fin_hz / fout_hz;
+  st->ntaps = ntaps;
+  st->half = ntaps / 2;
+  st->cutoff = cutoff;
+  return st;
+}
+
+void iq_resamp_zp_free(iq_resamp_zp_t *st) { free(st); }
+
+size_t iq_resamp_process_zero_phase(iq_resamp_zp_t *st, const float32_t *in, size_t Nin, float32_t *out, size_t Nout_cap)
+{
+  if (!st || !in || !out || Nin == 0 || Nout_cap == 0) return 0;  // up_sample.c:116-118
+  if (st->ntaps > kResampMaxTaps) { set_error("iq_resamp_process_zero_phase: at most %d taps", kResampMaxTaps); return 0; }
+  if (Nin > 0x7FFFFFFFu) return 0;
+  const uint32_t cap = Nout_cap > 0x7FFFFFFFu ? 0x7FFFFFFFu : (uint32_t)Nout_cap;
+  return resamp_host(st->fin, st->fout, in, (uint32_t)Nin, out, cap, "iq_resamp_process_zero_phase", st->ntaps, st->cutoff);
 }
 
 }  // extern "C"

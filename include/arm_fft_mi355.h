@@ -29,6 +29,7 @@
 
 #include <stddef.h>
 #include <stdint.h>
+#include <stdio.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -343,6 +344,15 @@ arm_status gnss_decode_ors_iq_dev(const uint8_t *data_dev, uint32_t byte_length,
 arm_status gnss_acquire(gnss_acq_plan *plan, const float32_t *signal, uint32_t n_scenes, gnss_acq_result *best,
                         gnss_acq_result *all);
 
+/* Multi-GPU search from a plain C host (no Python, no RCCL): plans[i] was created with GPU i current
+ * (same geometry, PRN list and Doppler grid everywhere).  Plan i searches the i-th contiguous share of the Doppler
+ * bins on its own device from its own host thread; the signal is copied to every device, nothing crosses between
+ * GPUs, and the per-(scene, PRN) winners are merged on the host by the single-GPU rule (largest peak, lowest bin
+ * on ties): best[scene * n_prn + p] equals what gnss_acquire returns on one plan.  Replaces the reference's serial
+ * (prn, doppler) loop, CMSIS/CMSIS.cpp:706-737.  Two plans on ONE device are allowed (they share it). */
+arm_status gnss_acquire_multi(gnss_acq_plan *const *plans, uint32_t n_plans, const float32_t *signal, uint32_t n_scenes,
+                              gnss_acq_result *best);
+
 /* Device-side counterparts of the reference's helpers, exported so each can be checked on its own:
  * getCode (gnss_codes.c:969-1030): out_dev[num * samples_per_chip] ints, +1/-1;
  * synth_gps_prn (gnss_codes.c:1066-1071, mix_prn :1032-1063): replica_dev[size] complex;
@@ -352,6 +362,32 @@ arm_status gnss_get_code_dev(int32_t num, int32_t samples_per_chip, int32_t prn,
 arm_status gnss_synth_gps_prn_dev(int32_t prn, float32_t doppler, uint32_t size, float32_t *replica_dev, int32_t samples_per_chip);
 arm_status gnss_find_top2_peaks_dev(const float32_t *data_dev, int32_t is_complex, int32_t data_size, int32_t pk_sep, uint32_t batch,
                                     gnss_top2 *peaks_dev, void *stream);
+
+/* The reference's own names for those helpers (Include/gnss_codes.h:62-126), host pointers; `c32` arrays are passed
+ * as interleaved float32_t I/Q (Include/cplx_types.h:9: struct { float r, i; }, same memory).  Each stages its
+ * arguments to the current device, runs the kernel above and copies the result back.
+ *   getCode                 gnss_codes.c:969-1030   out[num * samplesPerChip] ints, +1 / -1
+ *   synth_gps_prn           :1066-1071 (mix_prn :1032-1063)   replica[size] c32; carrier by direct evaluation of the
+ *                           double phase instead of the reference's renormalised recursive phasor (<= 1.2e-7 apart)
+ *   find_top2_peaks_cplx / _real   :1144-1190   same values and indices as the sequential loop, ties included;
+ *                           data_size <= 16384; fp_out (optional) receives the reference's "m, magnitude" dump;
+ *                           returns -1 on a bad argument or when the GPU cannot run (0 = success)
+ *   compute_snr_cplx / _real       :1110-1142   10 log10(peak / mean off-peak magnitude)
+ *   InterpolateCodePhase    :1096-1108   scalar formula on three doubles (host arithmetic: no data to move)
+ * The void / double entry points abort() with a message when the GPU cannot run them (see Conventions). */
+typedef struct {          /* Include/gnss_codes.h:42-47 */
+  size_t idx1;
+  float val1;
+  size_t idx2;
+  float val2;
+} top2_pks;
+void getCode(int num, int samplesPerChip, const int prn, int *out);
+void synth_gps_prn(int prn, float doppler, size_t size, float32_t *replica, int spc);
+int find_top2_peaks_cplx(const float32_t *data, int data_size, int pk_sep, top2_pks *peaks, FILE *fp_out);
+int find_top2_peaks_real(const float32_t *data, int data_size, int pk_sep, top2_pks *peaks, FILE *fp_out);
+double compute_snr_cplx(float32_t *convol, int cov_size, double peak, int peak_loc);
+double compute_snr_real(float32_t *convol, int cov_size, double peak, int peak_loc);
+double InterpolateCodePhase(uint32_t index, double earlyPower, double promptPower, double latePower);
 
 /* ---- codes of any length through caller-supplied replicas ----
  * The fork correlates L5 / E5a codes (10230 chips at 10.23 Msps) by resampling signal and replica
@@ -373,6 +409,22 @@ arm_status gnss_acq_plan_create_replicas(gnss_acq_plan **plan, uint32_t fft_len,
  * registers are not reset at the 10230-chip boundary (as in the reference). */
 arm_status gnss_l5_generate_I_dev(int32_t prn, uint32_t n_chips, int8_t *out_dev);
 
+/* Galileo E1-B CBOC replica: synth_e1b_prn (gnss_codes.c:920-965) = code chip x
+ * cboc_e1b_weight (:253-260: sqrt(10/11) BOC(1,1) - sqrt(1/11) BOC(6,1), boc_sign :247-251) x carrier at
+ * `doppler`, fs = 4.092 MHz, code and carrier phase 0, data bit +1, with the reference's float phase
+ * recursions.  The reference reads the code table from C:/work/Baseband/HEX_E1B.txt (:930), which is not
+ * part of it; here the caller supplies the chips: codes_dev = n_codes x 4092 chips (+1 / -1 as int8,
+ * the rows of E1B_Code[][]) on the device, replica_dev = n_codes x size complex f32.  With doppler = 0
+ * and size = 4096 (4092 samples + the reference's zero padding is NOT added: sample n >= 4092 continues
+ * the periodic code) the output feeds gnss_acq_plan_create_replicas.  Asynchronous on `stream`, no allocation. */
+arm_status gnss_e1b_cboc_replica_dev(const int8_t *codes_dev, uint32_t n_codes, float32_t doppler, uint32_t size,
+                                     float32_t *replica_dev, void *stream);
+/* hexstream_to_e1b_chips / _e5a_chips / _e5a_qp_chips (gnss_codes.c:276-325; hex_nibble :234-239,
+ * logic_to_chip_icd :243-245), generalised over the code length (4092 E1-B, 10230 E5a ...): the ICD's hex
+ * text -> chips, MSB first within a nibble, logic 1 -> -1, any non-hex character skipped.  Host-side.
+ * Returns 0, or -1 when the stream holds fewer than code_len bits. */
+int gnss_hexstream_to_chips(const char *hex_stream, int8_t *chips, int32_t code_len);
+
 /* ---- zero-phase I/Q resampler ----
  * Include/gnss_codes.h:97-99, bodies gnss_codes.c:868-904 over iq_resamp_zp_init /
  * iq_resamp_process_zero_phase [Include/up_sample.h:20-24, up_sample.c:31-157].  `in`/`out` are
@@ -388,6 +440,21 @@ void up_sample_10k_to_16k(float32_t *in, float32_t *out);
 arm_status iq_resamp_zero_phase_dev(double fin_hz, double fout_hz, int32_t ntaps, double cutoff, const float32_t *in_dev, uint32_t n_in,
                                     float32_t *out_dev, uint32_t n_out_cap, uint32_t batch, uint32_t *n_out, void *stream);
 uint32_t iq_resamp_zero_phase_count(double fin_hz, double fout_hz, int32_t ntaps, double cutoff, uint32_t n_in, uint32_t n_out_cap);
+/* The reference's own resampler object and calls (Include/up_sample.h:11-24; bodies up_sample.c:31-48, :115-157),
+ * host pointers, `in` / `out` as interleaved float32_t I/Q: init returns NULL for odd or < 4 taps or a cutoff outside
+ * (0, 0.5]; process returns the number of samples written, min(llround(Nin * fout / fin), Nout_cap) (0 on a bad
+ * argument); at most 64 taps here.  The filtering runs on the GPU (iq_resamp_zero_phase_dev, one block). */
+typedef struct {
+  double fin;     /* input sample rate (Hz) */
+  double fout;    /* output sample rate (Hz) */
+  double dt;      /* fin / fout */
+  int ntaps;
+  int half;
+  double cutoff;
+} iq_resamp_zp_t;
+iq_resamp_zp_t *iq_resamp_zp_init(double fin_hz, double fout_hz, int ntaps, double cutoff);
+size_t iq_resamp_process_zero_phase(iq_resamp_zp_t *st, const float32_t *in, size_t Nin, float32_t *out, size_t Nout_cap);
+void iq_resamp_zp_free(iq_resamp_zp_t *st);
 
 /* ---- measurement wire format "msb" (Include/msb_funcs.h, Source/TransformFunctions/msb_funcs.c) ----
  * The fork's downstream tools read acquisition results as a bit-packed record: a 32-bit GPS PRN

@@ -120,6 +120,18 @@ double orc_compute_snr_cplx(const orc_c32 *conv, int n, double peak, int peak_lo
   return 10.0 * log10(peak / mean);
 }
 
+/* compute_snr_real (gnss_codes.c:1127-1142): the same on real magnitudes */
+double orc_compute_snr_real(const float *conv, int n, double peak, int peak_loc)
+{
+  double sum = 0;
+  for (int i = 0; i < n; i++) {
+    float magn = conv[i];
+    if (abs(i - peak_loc) > 2) sum += magn;
+  }
+  double mean = sum / (n - 5);
+  return 10.0 * log10(peak / mean);
+}
+
 /* InterpolateCodePhase (gnss_codes.c:1096-1108) */
 double orc_interpolate_code_phase(uint32_t index, double early, double prompt, double late)
 {
@@ -479,4 +491,65 @@ long orc_up_sample_n_to_m(const orc_c32 *in, int n_in, orc_c32 *out, int m_out)
 long orc_up_sample_10k_to_16k(const orc_c32 *in, orc_c32 *out)
 {
   return orc_iq_resamp_zero_phase(10230e3, 16384e3, 12, 0.45, in, 10230, out, llround(10230 * (16384e3 / 10230e3)) + 8);
+}
+
+/* ---- Galileo E1-B CBOC replica (parity unpinned: the reference holds no vector
+ * for it and its code tables HEX_E1B.txt are outside the mount) ---- */
+/* hex_nibble + hexstream_to_e1b_chips (gnss_codes.c:234-239, :276-289; the E5a / E5-QP twins :299-325
+ * differ only in the length): hex digits -> chips, MSB first within a nibble, logic 1 -> -1, logic 0 -> +1
+ * (logic_to_chip_icd :243-245); any other character is skipped.  0 on success, -1 if the stream is short. */
+int orc_hexstream_to_chips(const char *hex_stream, signed char *chips, int code_len)
+{
+  int chip_idx = 0;
+  for (const char *p = hex_stream; *p && chip_idx < code_len; ++p) {
+    const int c = (unsigned char)*p;
+    int v;
+    if (c >= '0' && c <= '9') v = c - '0';
+    else if (c >= 'A' && c <= 'F') v = 10 + (c - 'A');
+    else if (c >= 'a' && c <= 'f') v = 10 + (c - 'a');
+    else continue;
+    for (int b = 3; b >= 0 && chip_idx < code_len; --b) chips[chip_idx++] = ((v >> b) & 1) ? (signed char)-1 : (signed char)+1;
+  }
+  return chip_idx == code_len ? 0 : -1;
+}
+
+/* boc_sign (gnss_codes.c:247-251) and cboc_e1b_weight (:253-260): sqrt(10/11) BOC(1,1) minus sqrt(1/11) BOC(6,1) */
+static int boc_sign_f(int m, float u)
+{
+  if (m <= 0) return +1;
+  int k = (int)floorf(2.0f * m * u);
+  return (k & 1) ? -1 : +1;
+}
+float orc_cboc_e1b_weight(float u)
+{
+  const float w1 = 0.9534625892455923f, w6 = 0.3015113445777636f;
+  return w1 * (float)boc_sign_f(1, u) - w6 * (float)boc_sign_f(6, u);
+}
+
+/* synth_e1b_prn (gnss_codes.c:920-965) with the code table handed in (`ca` = the 4092 chips of one PRN,
+ * E1B_Code[prn] in the reference): fs 4.092 MHz, chip rate 1.023 MHz, code phase and carrier phase start at 0,
+ * FLOAT recursions for both, carrier through the double sin/cos of sincosf_fast (:573-576). */
+void orc_synth_e1b_prn(const signed char *ca, float doppler, size_t N, orc_c32 *out)
+{
+  const float PI_F = 3.14159265358979f; /* Include/gnss_codes.h:33 */
+  const float fs_hz = 4.092e6f, code_rate_cps = 1.023e6f;
+  const int L = 4092;
+  float dchips = code_rate_cps / fs_hz;
+  float dphia = 2.0f * (float)PI_F * (doppler) / fs_hz;
+  float chips = 0.0f, phia = 0.0f;
+  for (size_t n = 0; n < N; ++n) {
+    float frac = chips - floorf(chips);
+    int idx = (int)floorf(chips); /* code_chip_at :265-270 */
+    if (idx >= L) idx -= L;
+    else if (idx < 0) idx += L;
+    float ampa = (float)ca[idx] * orc_cboc_e1b_weight(frac);
+    float sa = (float)sin(phia), caph = (float)cos(phia);
+    out[n].r = ampa * caph;
+    out[n].i = ampa * sa;
+    chips += dchips;
+    if (chips >= L) chips -= L;
+    else if (chips < 0) chips += L;
+    phia += dphia;
+    if (phia > 1e9f || phia < -1e9f) phia = fmodf(phia, 2.0f * PI_F);
+  }
 }
