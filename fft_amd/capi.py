@@ -105,7 +105,7 @@ EXPORTED_SYMBOLS = (
     + ["arm_rfft_fast_init_f32", "arm_rfft_fast_f32", "arm_rfft_fast_batch_f32", "arm_rfft_fast_f32_dev"]
     + ["arm_rfft_fast_init_%d_f32" % n for n in _RFFT_SIZES]
     + ["arm_cfft_radix2_init_f32", "arm_cfft_radix2_f32", "arm_cfft_radix2_batch_f32", "arm_cfft_radix2_f32_dev"]
-    + ["arm_cfft_init_u32_f32", "arm_cfft_u32_f32_dev", "arm_cfft_u32_batch_f32"]
+    + ["arm_cfft_init_u32_f32", "arm_cfft_u32_f32_dev", "arm_cfft_u32_batch_f32", "arm_cfft_u32_f32_noalloc_prepare", "arm_cfft_u32_f32_noalloc_dev"]
     + ["gnss_acq_plan_create", "gnss_acq_plan_destroy", "gnss_acq_plan_set_peak_separation", "gnss_acq_plan_code_spectra_dev",
        "gnss_acquire_dev", "gnss_acquire_ors_dev", "gnss_decode_ors_iq_dev", "gnss_acq_workspace_bytes", "gnss_acquire_groups_dev", "gnss_acquire", "gnss_get_code_dev", "gnss_synth_gps_prn_dev", "gnss_find_top2_peaks_dev"]
     + ["arm_rfft_init_q15", "arm_rfft_init_q31", "arm_rfft_q15", "arm_rfft_q31", "arm_rfft_batch_q15", "arm_rfft_batch_q31",
@@ -170,6 +170,8 @@ def _load():
     L.arm_cfft_init_u32_f32.argtypes, L.arm_cfft_init_u32_f32.restype = [POINTER(U), u32], c_int
     L.arm_cfft_u32_f32_dev.argtypes, L.arm_cfft_u32_f32_dev.restype = [POINTER(U), c_void_p, c_void_p, u32, u8, c_void_p], c_int
     L.arm_cfft_u32_batch_f32.argtypes, L.arm_cfft_u32_batch_f32.restype = [POINTER(U), c_void_p, u32, u8], c_int
+    L.arm_cfft_u32_f32_noalloc_prepare.argtypes, L.arm_cfft_u32_f32_noalloc_prepare.restype = [u32], c_int
+    L.arm_cfft_u32_f32_noalloc_dev.argtypes, L.arm_cfft_u32_f32_noalloc_dev.restype = [POINTER(U), c_void_p, u32, u8, c_void_p], c_int
     i32 = c_int32
     L.gnss_acq_plan_create.argtypes = [POINTER(c_void_p), u32, u32, u32, u32, c_void_p, u32, c_void_p, u32]
     L.gnss_acq_plan_create.restype = c_int

@@ -384,6 +384,20 @@ static const float2 *dev_tw_rfft(int logn_real)
 }
 
 const float2 *dev_twiddle_f32(int logn) { return dev_tw_f32(logn); }
+static const float2 *dev_tw_lo(int logn);
+const float2 *dev_twiddle_lo(int logn) { return dev_tw_lo(logn); }
+const float2 *dev_twiddle_f32_peek(int logn)
+{
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev || logn < 0 || logn > kMaxLog) return nullptr;
+  return slot_peek(g_dev[dev].tw_f32[logn]);
+}
+const float2 *dev_twiddle_lo_peek(int logn)
+{
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev || logn < 0 || logn > kMaxLargeLog) return nullptr;
+  return slot_peek(g_dev[dev].tw_lo[logn]);
+}
 
 static const float2 *dev_tw_lo(int logn)
 {

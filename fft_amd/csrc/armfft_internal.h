@@ -17,6 +17,11 @@ bool hip_ok(hipError_t e, const char *what);
 
 // per-device cached table exp(-2 pi i m / 2^logn), m < 2^logn (armfft_abi.cpp); nullptr + error on failure
 const float2 *dev_twiddle_f32(int logn);
+// three-level table of W_N for the four-step kernels (armfft_large.hip), same caching
+const float2 *dev_twiddle_lo(int logn);
+// the same tables if they already exist on the current device, else nullptr: never allocate, set no error
+const float2 *dev_twiddle_f32_peek(int logn);
+const float2 *dev_twiddle_lo_peek(int logn);
 
 // ---- kernel launchers (no allocation, asynchronous on the stream) ----
 // f32 complex, in place; tw = device table of N entries exp(-2 pi i m / N)

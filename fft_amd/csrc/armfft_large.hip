@@ -286,3 +286,102 @@ hipError_t launch_cfft_large_f32(int logn, float2 *data, float2 *work, const flo
 }
 
 }  // namespace armfft
+
+// ------------------------------------------------------------------------------------------
+// allocation-free variant of arm_cfft_u32_f32_dev (no counterpart in the reference; for callers that
+// cannot call hipMalloc: code under HIP graph capture, tight serving loops, harnesses that forbid it)
+// ------------------------------------------------------------------------------------------
+// arm_cfft_u32_f32_dev needs a caller-provided workspace of the data's size for the intermediate of the
+// four-step decomposition.  Here that workspace is a file-scope device array: 64 MiB per GPU, held from
+// the moment the code object is loaded on that GPU until the process ends, shared by every call on that
+// GPU (calls that overlap on one GPU race on it; one stream, or events between streams, order them).
+// Pass 1 overwrites every word of the part pass 2 then reads, so nothing needs clearing between calls.
+// In host code `armfft_noalloc_scratch` is only a handle to the symbol, not a device address: the per-device
+// address comes from hipGetSymbolAddress (each GPU holds its own copy at its own address) and only that
+// pointer is ever handed to kernels.
+namespace {
+constexpr size_t kNoAllocScratchBytes = (size_t)64 << 20;                         // 2^23 complex f32 points
+constexpr uint64_t kNoAllocMaxPoints = kNoAllocScratchBytes / sizeof(float2);
+}  // namespace
+static __device__ __align__(256) unsigned char armfft_noalloc_scratch[kNoAllocScratchBytes];
+
+namespace {
+std::atomic<float2 *> g_scratch_ptr[16];   // per device, resolved once with that device current
+
+float2 *noalloc_scratch(int dev)
+{
+  using namespace armfft;
+  if (dev < 0 || dev >= 16) { set_error("device index %d out of range", dev); return nullptr; }
+  float2 *p = g_scratch_ptr[dev].load(std::memory_order_acquire);
+  if (p) return p;
+  void *q = nullptr;
+  if (!hip_ok(hipGetSymbolAddress(&q, HIP_SYMBOL(armfft_noalloc_scratch)), "hipGetSymbolAddress(scratch)") || !q) return nullptr;
+  g_scratch_ptr[dev].store(reinterpret_cast<float2 *>(q), std::memory_order_release);   // same value from any racing thread
+  return reinterpret_cast<float2 *>(q);
+}
+}  // namespace
+
+extern "C" {
+
+// set-up (may allocate: the twiddle tables of this size on the current device): builds the tables, resolves the
+// scratch address and runs one forward and one inverse transform inside the scratch array so that every
+// per-kernel attribute is set before the first allocation-free call
+arm_status arm_cfft_u32_f32_noalloc_prepare(uint32_t fftLen)
+{
+  using namespace armfft;
+  if (fftLen == 0 || (fftLen & (fftLen - 1))) { set_error("arm_cfft_u32_f32_noalloc_prepare: fftLen %u is not a power of two", fftLen); return ARM_MATH_ARGUMENT_ERROR; }
+  int l = 0;
+  while ((1u << l) < fftLen) l++;
+  if (l < kMinLargeLog || l > kMaxLargeLog) { set_error("arm_cfft_u32_f32_noalloc_prepare: fftLen %u outside 2^%d..2^%d", fftLen, kMinLargeLog, kMaxLargeLog); return ARM_MATH_ARGUMENT_ERROR; }
+  int dev = 0;
+  if (!hip_ok(hipGetDevice(&dev), "hipGetDevice")) return ARM_MATH_ARGUMENT_ERROR;
+  float2 *scr = noalloc_scratch(dev);
+  if (!scr) return ARM_MATH_ARGUMENT_ERROR;
+  const int l2 = l / 2, l1 = l - l2;
+  const float2 *tw1 = dev_twiddle_f32(l1), *tw2 = dev_twiddle_f32(l2), *big = dev_twiddle_lo(l);
+  if (!tw1 || !tw2 || !big) return ARM_MATH_ARGUMENT_ERROR;
+  // data = first half of the scratch array, workspace = second half (2^22 points x 8 bytes = 32 MiB each at most)
+  float2 *work = scr + kNoAllocMaxPoints / 2;
+  bool ok = hip_ok(hipMemsetAsync(scr, 0, sizeof(float2) * (size_t)fftLen, nullptr), "hipMemsetAsync(scratch)") &&
+            hip_ok(launch_cfft_large_f32(l, scr, work, tw1, tw2, big, 1, false, nullptr), "four-step warm-up (forward)") &&
+            hip_ok(launch_cfft_large_f32(l, scr, work, tw1, tw2, big, 1, true, nullptr), "four-step warm-up (inverse)") &&
+            hip_ok(hipStreamSynchronize(nullptr), "synchronise");
+  return ok ? ARM_MATH_SUCCESS : ARM_MATH_ARGUMENT_ERROR;
+}
+
+// The allocation-free call itself: no hipMalloc / hipFree / allocating routine on any path.  Requires
+// arm_cfft_u32_f32_noalloc_prepare(S->fftLen) earlier on this device, batch * fftLen <= 2^23 points.
+arm_status arm_cfft_u32_f32_noalloc_dev(const arm_cfft_instance_u32_f32 *S, float32_t *p, uint32_t batch, uint8_t ifft, void *stream)
+{
+  using namespace armfft;
+  const char *who = "arm_cfft_u32_f32_noalloc_dev";
+  if (!S || !p) { set_error("%s: null argument", who); return ARM_MATH_ARGUMENT_ERROR; }
+  if (((uintptr_t)p & 15u) != 0) { set_error("%s: device pointer %p is not 16-byte aligned", who, (void *)p); return ARM_MATH_ARGUMENT_ERROR; }
+  const uint32_t n = S->fftLen;
+  int l = 0;
+  while (l < 31 && (1u << l) < n) l++;
+  if (n == 0 || (n & (n - 1)) || l < kMinLargeLog || l > kMaxLargeLog) {
+    set_error("%s: fftLen %u is not a power of two in 2^%d..2^%d (smaller transforms need no workspace: arm_cfft_f32_dev)", who, n, kMinLargeLog, kMaxLargeLog);
+    return ARM_MATH_ARGUMENT_ERROR;
+  }
+  if ((uint64_t)batch * n > kNoAllocMaxPoints) {
+    set_error("%s: batch %u x fftLen %u = %llu points exceeds the built-in workspace of %llu points (64 MiB); split the batch or use arm_cfft_u32_f32_dev", who,
+              batch, n, (unsigned long long)batch * n, (unsigned long long)kNoAllocMaxPoints);
+    return ARM_MATH_ARGUMENT_ERROR;
+  }
+  if (batch == 0) return ARM_MATH_SUCCESS;
+  int dev = 0;
+  if (!hip_ok(hipGetDevice(&dev), "hipGetDevice")) return ARM_MATH_ARGUMENT_ERROR;
+  float2 *scr = noalloc_scratch(dev);
+  if (!scr) return ARM_MATH_ARGUMENT_ERROR;
+  const int l2 = l / 2, l1 = l - l2;
+  const float2 *tw1 = dev_twiddle_f32_peek(l1), *tw2 = dev_twiddle_f32_peek(l2), *big = dev_twiddle_lo_peek(l);
+  if (!tw1 || !tw2 || !big) {
+    set_error("%s: no plan for fftLen %u on device %d: call arm_cfft_u32_f32_noalloc_prepare(%u) once first (this entry point never allocates)", who, n, dev, n);
+    return ARM_MATH_ARGUMENT_ERROR;
+  }
+  hipError_t e = launch_cfft_large_f32(l, reinterpret_cast<float2 *>(p), scr, tw1, tw2, big, batch, ifft != 0, (hipStream_t)stream);
+  return hip_ok(e, "cfft_large_f32 launch") ? ARM_MATH_SUCCESS : ARM_MATH_ARGUMENT_ERROR;
+}
+
+}  // extern "C"

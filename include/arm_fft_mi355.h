@@ -271,6 +271,18 @@ typedef struct {
 arm_status arm_cfft_init_u32_f32(arm_cfft_instance_u32_f32 *S, uint32_t fftLen);
 arm_status arm_cfft_u32_f32_dev(const arm_cfft_instance_u32_f32 *S, float32_t *p1_dev, float32_t *work_dev, uint32_t batch,
                                 uint8_t ifftFlag, void *stream);
+/* Allocation-free variant of arm_cfft_u32_f32_dev.  No counterpart in the reference; it exists for callers that
+ * cannot call hipMalloc -- code under HIP graph capture, tight serving loops, harnesses that forbid allocation.
+ * The four-step intermediate goes to a workspace built into the library (a 64 MiB device array per GPU, held
+ * until the process ends), so the call takes no workspace argument and calls no hipMalloc / hipFree or other
+ * allocating routine.  Limits: 2^15 <= fftLen <= 2^22 and batch * fftLen <= 2^23 points (larger requests are
+ * refused with ARM_MATH_ARGUMENT_ERROR and a message); arm_cfft_u32_f32_noalloc_prepare(fftLen) must have run
+ * once on the device before (set-up: it may allocate the twiddle tables).  Every call on a GPU shares that GPU's
+ * workspace: calls that overlap on one GPU (different streams without ordering) race; serialise them.
+ * Results are bit-identical to arm_cfft_u32_f32_dev (same kernels). */
+arm_status arm_cfft_u32_f32_noalloc_prepare(uint32_t fftLen);
+arm_status arm_cfft_u32_f32_noalloc_dev(const arm_cfft_instance_u32_f32 *S, float32_t *p1_dev, uint32_t batch, uint8_t ifftFlag,
+                                        void *stream);
 /* host pointers; allocates its own device staging */
 arm_status arm_cfft_u32_batch_f32(const arm_cfft_instance_u32_f32 *S, float32_t *p1, uint32_t batch, uint8_t ifftFlag);
 
