@@ -64,6 +64,10 @@ def parse():
     ap.add_argument("--workload", default="cfft_f32_4096x65536",
                     help="one of %s, or <cfft_f32|cfft_q15|cfft_q31|rfft_f32>_<N>x<batch> for tuning runs" % ", ".join(sorted(WORKLOADS)))
     ap.add_argument("--batch", type=int, default=0, help="override the batch (debug only; the line says so)")
+    ap.add_argument("--preheat-ms", type=float, default=100.0,
+                    help="untimed launches before the W warm-up steps until this much wall time has passed: the GPU's clock/power "
+                         "management takes ~25 ms of continuous load to settle (profiles/r02_cfft_f32_4096_launch_series.txt: launches "
+                         "4-30 of a cold start run 5-20 %% slow), so a short run would time the transient, not the sustained rate")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the other configs' measurements (headline workload, N = 1)")
     ap.add_argument("--extra-steps", type=int, default=5)
@@ -332,19 +336,18 @@ def build_workload(name, wl, rank, stream, dop_range=None):
         w.chunk = max(1, int(180 // growth))
         data = ((torch.rand((batch, 2 * n), device="cuda", generator=gen) * 2 - 1) * 2.0 ** -100).contiguous()
         w.step = lambda: lib.arm_cfft_f32_dev(ctypes.byref(S), vp(data.data_ptr()), batch, 0, 1, stream)
-        _half = 2.0 ** (-(growth * w.chunk) / 2.0)
-        w.rescale = lambda: data.mul_(_half).mul_(_half)
+        w.rescale = lambda p: data.mul_(2.0 ** (-(growth * p) / 2.0)).mul_(2.0 ** (-(growth * p) / 2.0))   # p passes of growth, exact powers of two
         w.bytes_per_xform, w.flops_per_xform = 16 * n, 5.0 * n * np.log2(n)
         w.kernel_name = "cfft_f32_kernel<%d, false>" % int(np.log2(n))
         w.data = data
     elif kind == "large":
         S = fft_amd.arm_cfft_instance_u32_f32()
         assert lib.arm_cfft_init_u32_f32(ctypes.byref(S), n) == 0
-        w.chunk = 4
-        data = ((torch.rand((batch, 2 * n), device="cuda", generator=gen) * 2 - 1) * 2.0 ** -48).contiguous()
+        w.chunk = max(1, int(180 // (int(np.log2(n)) / 2.0)))   # 16 passes at 2^22 points
+        data = ((torch.rand((batch, 2 * n), device="cuda", generator=gen) * 2 - 1) * 2.0 ** -100).contiguous()
         work = torch.empty_like(data)
         w.step = lambda: lib.arm_cfft_u32_f32_dev(ctypes.byref(S), vp(data.data_ptr()), vp(work.data_ptr()), batch, 0, stream)
-        w.rescale = lambda: data.mul_(2.0 ** (-(int(np.log2(n)) // 2) * w.chunk))
+        w.rescale = lambda p: data.mul_(2.0 ** (-(int(np.log2(n)) / 2.0) * p))
         # algorithmic bytes per SURVEY 8(d): 16*N per transform; the four-step moves every point twice
         w.bytes_per_xform, w.flops_per_xform = 16 * n, 5.0 * n * np.log2(n)
         w.kernel_name = "fourstep_pass_kernel<%d|%d, 1|2, false> (two launches per step)" % ((int(np.log2(n)) + 1) // 2, int(np.log2(n)) // 2)
@@ -421,12 +424,24 @@ def build_workload(name, wl, rank, stream, dop_range=None):
     return w
 
 
+def preheat(w, ms, state, ev0, ev1):
+    """Untimed launches of the workload's own step for `ms` milliseconds of wall time (see --preheat-ms); returns the count."""
+    import torch
+    n, t_end = 0, time.perf_counter() + ms / 1e3
+    while ms > 0 and time.perf_counter() < t_end:
+        run_steps(w, 4, False, state, ev0, ev1)
+        torch.cuda.synchronize()
+        n += 4
+    return n
+
+
 def run_steps(w, m, timed, state, ev0, ev1):
     """m passes of w.step(); timed: HIP events on the launch stream around the launches (the rescale that keeps
     f32 data finite stays outside the events, inside the caller's wall clock)."""
     import fft_amd
+    state.setdefault("since", 0)   # passes since the data were last scaled back
     while m > 0:
-        todo = min(m, w.chunk - state["passes"] % w.chunk) if w.rescale else m
+        todo = min(m, w.chunk - state["since"]) if w.rescale else m
         if timed:
             ev0.record()
         for _ in range(todo):
@@ -434,12 +449,22 @@ def run_steps(w, m, timed, state, ev0, ev1):
         if timed:
             ev1.record()
         state["passes"] += todo
+        state["since"] += todo
         m -= todo
-        if w.rescale and state["passes"] % w.chunk == 0:
-            w.rescale()
+        if w.rescale and state["since"] >= w.chunk:
+            w.rescale(state["since"])
+            state["since"] = 0
         if timed:
             ev1.synchronize()
             state["kernel_ms"] += ev0.elapsed_time(ev1)
+
+
+def settle_scale(w, k, state):
+    """Before a timed region of k steps: scale the f32 data back now (untimed) if the region would otherwise have to do it
+    in the middle, so that the timed region holds transforms only whenever k fits one chunk."""
+    if w.rescale and state.get("since", 0) and state["since"] + k > w.chunk >= k:
+        w.rescale(state["since"])
+        state["since"] = 0
 
 
 def roofline_of(w, launch_s, traffic_table):
@@ -462,7 +487,7 @@ def roofline_of(w, launch_s, traffic_table):
 EXTRA_WORKLOADS = ["cfft_q15_4096x65536", "cfft_q31_4096x65536", "rfft_f32_16384x16384", "cfft_f32_4194304x8", "gnss_acq_gps_l1_x256"]
 
 
-def measure_extra(name, steps, stream, traffic_table):
+def measure_extra(name, steps, stream, traffic_table, preheat_ms=50.0):
     """One of the other BASELINE configs, measured like the headline (HIP events on the launch stream, wall clock
     around them), a few steps, memory released afterwards."""
     import torch
@@ -470,7 +495,9 @@ def measure_extra(name, steps, stream, traffic_table):
     w = build_workload(name, wl, 0, stream)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     state = {"passes": 0, "kernel_ms": 0.0}
+    n_pre = preheat(w, preheat_ms, state, ev0, ev1)
     run_steps(w, 2, False, state, ev0, ev1)
+    settle_scale(w, steps, state)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run_steps(w, steps, True, state, ev0, ev1)
@@ -481,7 +508,7 @@ def measure_extra(name, steps, stream, traffic_table):
         metric, value, unit = "GNSS acquisition cells/s (PRN x Doppler bin x code phase)", round(w.batch * steps * 32 * 41 * 4096 / elapsed, 1), "cells/s"
     else:
         metric, value, unit = name + " GFLOP/s (5NlogN; real: 2.5NlogN)", round(w.batch * steps * w.flops_per_xform / elapsed / 1e9, 2), "GFLOP/s"
-    out = {"workload": name, "metric": metric, "value": value, "unit": unit, "steps": steps, "warmup": 2, "ms_per_step": round(1e3 * elapsed / steps, 4),
+    out = {"workload": name, "metric": metric, "value": value, "unit": unit, "steps": steps, "warmup": 2, "preheat_launches": n_pre, "ms_per_step": round(1e3 * elapsed / steps, 4),
            "dtype": w.dtype, "roofline": roofline_of(w, launch_s, traffic_table)}
     if w.kind == "gnss":
         from fft_amd import lib
@@ -542,7 +569,9 @@ def main():
     ev0 = torch.cuda.Event(enable_timing=True)
     ev1 = torch.cuda.Event(enable_timing=True)
     state = {"passes": 0, "kernel_ms": 0.0}
+    n_pre = preheat(w, args.preheat_ms, state, ev0, ev1)
     run_steps(w, W, False, state, ev0, ev1)
+    settle_scale(w, K, state)
     barrier()
     t0 = time.perf_counter()
     run_steps(w, K, True, state, ev0, ev1)
@@ -603,7 +632,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": args.workload, "fft_len": n, "batch_per_gpu": batch, "direction": "forward",
                        "in_place": kind != "rfft", "sharding": "independent batches per GPU, no collective",
-                       "output_finite": finite},
+                       "output_finite": finite,
+                       "preheat": "%d untimed launches (%.0f ms of wall time) before the %d warm-up steps, so that the timed steps see the "
+                                  "settled clocks of a sustained run (--preheat-ms 0 disables)" % (n_pre, args.preheat_ms, W)},
         }
         if shard_doppler:
             # the events bracket kernels AND the all-gather here: report the step time, not a kernel roofline of a partial search
@@ -623,7 +654,7 @@ def main():
             # the other configs, measured in this same run (the headline's memory is released first)
             del w
             torch.cuda.empty_cache()
-            line["extra"] = [measure_extra(nm, args.extra_steps, stream, traffic_table) for nm in EXTRA_WORKLOADS]
+            line["extra"] = [measure_extra(nm, args.extra_steps, stream, traffic_table, args.preheat_ms / 2) for nm in EXTRA_WORKLOADS]
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

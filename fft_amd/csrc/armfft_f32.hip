@@ -50,10 +50,17 @@ __device__ __forceinline__ int scrambled_pos(int k)
 // wave, table twiddles): there a wave instruction covers 64-byte segments, nt costs 15%, the
 // one-shot form without nt and LDS staging measured the same or slower.  16, 32 and 64 points are
 // staged through LDS with 16-byte accesses (nt pays at 16 points only).
+//   SPLIT     (one-shot sizes from 4096 points) the half-footprint exchange of fft_core_f32.hpp: real and imaginary parts
+//             cross the workgroup one after the other through an LDS image of N floats, so twice as many workgroups share
+//             a CU (LDS was the limit: 4096 points 4 -> 7 per CU, 16384 points 1 -> 2) and their HBM phases overlap each
+//             other's passes.  Same-box A/B (tools/fft_lab2, 2 GiB batches): 4096 0.770 -> 0.722 ms (frac 0.70 -> 0.74),
+//             8192 0.778 -> 0.743 (0.69 -> 0.72), 16384 1.126 -> 0.785 (0.48 -> 0.68; needs the 64-VGPR build, MINW 8,
+//             for two 1024-thread workgroups per CU).  2048 points lose 3 % and 1024 gain 1 %: left as they were.
+//   NESTED16  temp-free radix-16 twiddle products (see twpow_mul), SPLIT kernels only
 struct TuneBase {
   static constexpr unsigned LAZYMASK = 0;
   static constexpr int MINW = 4, AUX = 0;
-  static constexpr bool NESTED8 = false, ONESHOT = false;
+  static constexpr bool NESTED8 = false, NESTED16 = false, ONESHOT = false, SPLIT = false;
 };
 template <int LOGN> struct Tune : TuneBase {};
 template <> struct Tune<4> : TuneBase { static constexpr int AUX = 2; };
@@ -61,9 +68,9 @@ template <> struct Tune<8> : TuneBase { static constexpr unsigned LAZYMASK = ~0u
 template <> struct Tune<9> : TuneBase { static constexpr unsigned LAZYMASK = ~0u; static constexpr int AUX = 2; static constexpr bool ONESHOT = true; };
 template <> struct Tune<10> : TuneBase { static constexpr unsigned LAZYMASK = ~0u; static constexpr int AUX = 2; static constexpr bool ONESHOT = true; };
 template <> struct Tune<11> : TuneBase { static constexpr unsigned LAZYMASK = ~0u; static constexpr int MINW = 3, AUX = 2; static constexpr bool ONESHOT = true; };
-template <> struct Tune<12> : TuneBase { static constexpr unsigned LAZYMASK = ~0u; static constexpr int AUX = 2; static constexpr bool ONESHOT = true; };
-template <> struct Tune<13> : TuneBase { static constexpr unsigned LAZYMASK = ~0u; static constexpr bool ONESHOT = true, NESTED8 = true; };
-template <> struct Tune<14> : TuneBase { static constexpr unsigned LAZYMASK = ~0u; static constexpr int AUX = 2; static constexpr bool ONESHOT = true, NESTED8 = true; };
+template <> struct Tune<12> : TuneBase { static constexpr unsigned LAZYMASK = ~0u; static constexpr int AUX = 2; static constexpr bool ONESHOT = true, SPLIT = true, NESTED16 = true; };
+template <> struct Tune<13> : TuneBase { static constexpr unsigned LAZYMASK = ~0u; static constexpr int AUX = 2; static constexpr bool ONESHOT = true, SPLIT = true; };
+template <> struct Tune<14> : TuneBase { static constexpr unsigned LAZYMASK = ~0u; static constexpr int MINW = 8, AUX = 2; static constexpr bool ONESHOT = true, SPLIT = true, NESTED16 = true; };
 
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
@@ -200,6 +207,31 @@ __global__ __launch_bounds__(CPlan<LOGN>::T, Tune<LOGN>::MINW) void cfft_f32_ker
     };
     fft_block_tw<PL, false, false>(lds, twr, tid, ld, st);
   }
+}
+
+// One-shot kernel with the half-footprint exchange (Tune::SPLIT sizes).  The output order is a template parameter here:
+// with the three store forms in one kernel the register allocation is the worst of the three paths (112-123 VGPRs at 4096
+// points instead of ~70), which halves the workgroups per CU the split exchange exists to double.
+template <int LOGN, bool INV, int ORDER>
+__global__ __launch_bounds__(CPlan<LOGN>::T, Tune<LOGN>::MINW) void cfft_f32_split_kernel(float2 *__restrict__ data, const float2 *__restrict__ tw,
+                                                                                       uint32_t batch)
+{
+  using PL = CPlan<LOGN>;
+  static_assert(PL::TPB == 1, "one transform per workgroup");
+  extern __shared__ __attribute__((aligned(16))) float ldsf[];
+  const uint32_t g0 = blockIdx.x + blockIdx.y * gridDim.x;
+  if (g0 >= batch) return;
+  const int tid = threadIdx.x;
+  const __amdgpu_buffer_rsrc_t rs = transform_rsrc(data + (size_t)g0 * PL::N, PL::N * (uint32_t)sizeof(float2));
+  float2 v[16];
+  for_each_first_pass_input_split<PL>(tid, [&](int slot, int, int j, int roff) {
+    const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(rs, j * 8, roff * 8, Tune<LOGN>::AUX);
+    float2 x = make_float2(__uint_as_float(w[0]), __uint_as_float(w[1]));
+    if (INV) x.y = -x.y;
+    v[slot] = x;
+  });
+  BufferStore<LOGN, INV, ORDER, Tune<LOGN>::AUX> st{rs, 1.0f / (float)PL::N};
+  fft_block_split<PL, Tune<LOGN>::NESTED8, Tune<LOGN>::NESTED16>(v, ldsf, tw, tid, st);
 }
 
 // ---- real FFT: N real points <-> packed half spectrum, through an N/2-point complex FFT ----
@@ -490,6 +522,13 @@ static dim3 grid_for(uint32_t ngroups)
   return dim3(gx, (ngroups + gx - 1) / gx, 1);
 }
 
+template <int LOGN>
+static constexpr size_t cfft_lds_bytes()
+{
+  if constexpr (Tune<LOGN>::SPLIT) return SplitImage<CPlan<LOGN>>::LDS_BYTES;
+  else return CPlan<LOGN>::LDS_BYTES;
+}
+
 template <int LOGN, bool INV>
 static hipError_t launch_cfft_one(float2 *data, const float2 *tw, uint32_t batch, int order, hipStream_t stream)
 {
@@ -497,15 +536,32 @@ static hipError_t launch_cfft_one(float2 *data, const float2 *tw, uint32_t batch
   static std::atomic<bool> attr_done[16];  // zero-initialised; a racing second hipFuncSetAttribute is harmless
   int dev = 0;
   (void)hipGetDevice(&dev);
+  if constexpr (Tune<LOGN>::SPLIT) {
+    static std::atomic<bool> split_attr_done[16];
+    const size_t lds = SplitImage<PL>::LDS_BYTES;
+    if (lds > 48 * 1024 && dev < 16 && !split_attr_done[dev]) {
+      hipError_t e = hipFuncSetAttribute((const void *)cfft_f32_split_kernel<LOGN, INV, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e == hipSuccess) e = hipFuncSetAttribute((const void *)cfft_f32_split_kernel<LOGN, INV, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e == hipSuccess) e = hipFuncSetAttribute((const void *)cfft_f32_split_kernel<LOGN, INV, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      split_attr_done[dev] = true;
+    }
+    const dim3 grid = grid_for(batch);
+    if (order == 0) cfft_f32_split_kernel<LOGN, INV, 0><<<grid, PL::T, lds, stream>>>(data, tw, batch);
+    else if (order == 1) cfft_f32_split_kernel<LOGN, INV, 1><<<grid, PL::T, lds, stream>>>(data, tw, batch);
+    else cfft_f32_split_kernel<LOGN, INV, 2><<<grid, PL::T, lds, stream>>>(data, tw, batch);
+    return hipGetLastError();
+  }
   auto kern = cfft_f32_kernel<LOGN, INV>;
-  if (PL::LDS_BYTES > 48 * 1024 && dev < 16 && !attr_done[dev]) {
-    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PL::LDS_BYTES);
+  const size_t lds_bytes = cfft_lds_bytes<LOGN>();
+  if (lds_bytes > 48 * 1024 && dev < 16 && !attr_done[dev]) {
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
     attr_done[dev] = true;
   }
   const uint32_t ngroups = (batch + PL::TPB - 1) / PL::TPB;
   dim3 grid = grid_for(ngroups);
-  kern<<<grid, PL::T, PL::LDS_BYTES, stream>>>(data, tw, batch, ngroups, order);
+  kern<<<grid, PL::T, lds_bytes, stream>>>(data, tw, batch, ngroups, order);
   return hipGetLastError();
 }
 

@@ -250,6 +250,51 @@ struct TwRegs {
   }
 };
 
+// v[r] *= w^r, r < 2^LR, from the LR base powers bq[i] = w^(2^i) (see TwPow)
+// NESTED8 / NESTED16: radix-8 / radix-16 passes multiply the data by the bases directly (v5 = (v5 w1) w4 ...): a few more
+// complex multiplies (12 for 11, 32 for 26), the same number of roundings per leg or one more, and no product temporaries
+// at all -- for kernels at the edge of their register budget.
+template <int LR, bool NESTED8, bool NESTED16 = false>
+__device__ __forceinline__ void twpow_mul(const float2 *bq, float2 *v)
+{
+  if constexpr ((NESTED8 && LR == 3) || (NESTED16 && LR == 4)) {
+#pragma unroll
+    for (int r = 1; r < (1 << LR); r++) {
+      if (r & 1) v[r] = cmul(v[r], bq[0]);
+      if (r & 2) v[r] = cmul(v[r], bq[1]);
+      if (r & 4) v[r] = cmul(v[r], bq[2]);
+      if constexpr (LR == 4) {
+        if (r & 8) v[r] = cmul(v[r], bq[3]);
+      }
+    }
+    return;
+  }
+  float2 w[8];  // w[r], r < 8
+  w[1] = bq[0];
+  v[1] = cmul(v[1], w[1]);
+  if constexpr (LR >= 2) {
+    w[2] = bq[1];
+    w[3] = cmul(w[1], w[2]);
+    v[2] = cmul(v[2], w[2]);
+    v[3] = cmul(v[3], w[3]);
+  }
+  if constexpr (LR >= 3) {
+    w[4] = bq[2];
+    v[4] = cmul(v[4], w[4]);
+#pragma unroll
+    for (int r = 1; r < 4; r++) {
+      w[4 + r] = cmul(w[4], w[r]);
+      v[4 + r] = cmul(v[4 + r], w[4 + r]);
+    }
+  }
+  if constexpr (LR >= 4) {
+    const float2 w8 = bq[3];
+    v[8] = cmul(v[8], w8);
+#pragma unroll
+    for (int r = 1; r < 8; r++) v[8 + r] = cmul(v[8 + r], cmul(w8, w[r]));
+  }
+}
+
 // TwPow: the R-1 twiddles of one butterfly are the powers w, w^2 .. w^(R-1) of ONE number
 // w = W_N^stepk that depends only on the thread.  A persistent workgroup keeps w^1, w^2, w^4 (, w^8)
 // of every butterfly in registers (correctly rounded table values, loaded once per kernel) and
@@ -316,40 +361,7 @@ struct TwPow {
   __device__ __forceinline__ void mul(int q, float2 *v) const
   {
     constexpr int LR = PL::lr(P);
-    const float2 *bq = &b[P][q * nbase(LR)];
-    if constexpr (NESTED8 && LR == 3) {
-#pragma unroll
-      for (int r = 1; r < 8; r++) {
-        if (r & 1) v[r] = cmul(v[r], bq[0]);
-        if (r & 2) v[r] = cmul(v[r], bq[1]);
-        if (r & 4) v[r] = cmul(v[r], bq[2]);
-      }
-      return;
-    }
-    float2 w[8];  // w[r], r < 8
-    w[1] = bq[0];
-    v[1] = cmul(v[1], w[1]);
-    if constexpr (LR >= 2) {
-      w[2] = bq[1];
-      w[3] = cmul(w[1], w[2]);
-      v[2] = cmul(v[2], w[2]);
-      v[3] = cmul(v[3], w[3]);
-    }
-    if constexpr (LR >= 3) {
-      w[4] = bq[2];
-      v[4] = cmul(v[4], w[4]);
-#pragma unroll
-      for (int r = 1; r < 4; r++) {
-        w[4 + r] = cmul(w[4], w[r]);
-        v[4 + r] = cmul(v[4 + r], w[4 + r]);
-      }
-    }
-    if constexpr (LR >= 4) {
-      const float2 w8 = bq[3];
-      v[8] = cmul(v[8], w8);
-#pragma unroll
-      for (int r = 1; r < 8; r++) v[8 + r] = cmul(v[8 + r], cmul(w8, w[r]));
-    }
+    twpow_mul<LR, NESTED8>(&b[P][q * nbase(LR)], v);
   }
 };
 
@@ -515,6 +527,109 @@ __device__ __forceinline__ void fft_block_preloaded(float2 *v, float2 *lds, cons
   Preloaded ld;
   float2 twa[PL::E - 1], twb[PL::E - 1];
   PassLoop<PL, 0, false, LDS_OUT, HP, TW, Preloaded, Store, Hook>::run(v, lds, tw, tid, ld, st, twa, twb, hook);
+}
+
+// ---- half-footprint exchange: real parts and imaginary parts cross the workgroup one after the other ----
+// For transforms that fill the LDS (8192 / 16384 points: 64 / 128 KiB as float2) the number of workgroups per CU -- and
+// with it the overlap of one workgroup's HBM phases with another's passes -- is set by the LDS image.  Here the image is
+// N floats (+1 per 16 against bank conflicts: 68 KiB at 16384 points): every exchange between two passes runs twice
+// through the same buffer, first the real parts, then the imaginary parts,
+//     write re | barrier | read re | barrier | write im | barrier | read im | (barrier before the next exchange's writes)
+// which doubles the DS instruction count (4-byte instead of 8-byte accesses) and the barriers, and doubles the workgroups
+// per CU.  One transform per workgroup (TPB == 1), first-pass inputs preloaded.  Twiddles: the power bases of pass P + 1
+// (see TwPow) are fetched from the table right before the exchange that precedes it and are dead after its multiplies, so
+// at most 8 base values are live at a time instead of all passes' (32 registers at 16384 points): with the data's 32
+// registers the kernel fits the 64-VGPR budget of two 1024-thread workgroups per CU.
+template <class PL>
+struct SplitImage {
+  static_assert(PL::TPB == 1, "split exchange: one transform per workgroup");
+  static constexpr int ELEMS = PL::N + (PL::N >> 4);
+  static constexpr size_t LDS_BYTES = (size_t)ELEMS * sizeof(float);
+  static __device__ __forceinline__ int idx(int e) { return e + (e >> 4); }
+  static constexpr int delta(int c) { return c + (c >> 4); }  // c's set bits disjoint from e's (leg strides)
+};
+
+template <class PL, int P, bool NESTED8, bool NESTED16, class Store>
+__device__ __forceinline__ void fft_split_passes(float2 *v, float *ldsf, const float2 *__restrict__ tw, const float2 *bases, int tid, Store &st)
+{
+  using IM = SplitImage<PL>;
+  constexpr int LOGN = PL::LOGN, T = PL::T;
+  constexpr int LR = PL::lr(P), R = 1 << LR, NB = PL::E / R;
+  constexpr int LNS = PL::lns(P), NS = 1 << LNS;
+  constexpr int LNR = LOGN - LR;
+  constexpr bool FIRST = (P == 0), LAST = (P == PL::NPASS - 1);
+  if constexpr (!FIRST) {
+#pragma unroll
+    for (int q = 0; q < NB; q++) twpow_mul<LR, NESTED8, NESTED16>(bases + q * LR, v + q * R);
+  }
+#pragma unroll
+  for (int q = 0; q < NB; q++) butterfly<R>(v + q * R);
+  if constexpr (LAST) {
+#pragma unroll
+    for (int q = 0; q < NB; q++) {
+      const int j = (tid + q * T) & ((1 << LNR) - 1);
+      const int j0 = ((j >> LNS) << (LNS + LR)) + (j & (NS - 1));
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        if constexpr (store_is_split<Store>::value) st(0, j0, r << LNS, v[q * R + r]);
+        else st(0, j0 + (r << LNS), v[q * R + r]);
+      }
+    }
+  } else {
+    constexpr int LR1 = PL::lr(P + 1), R1 = 1 << LR1, NB1 = PL::E / R1, LNR1 = LOGN - LR1;
+    // scatter / gather addresses: one per butterfly, the legs are compile-time offsets
+    int wbase[NB], rbase[NB1];
+#pragma unroll
+    for (int q = 0; q < NB; q++) {
+      const int j = (tid + q * T) & ((1 << LNR) - 1);
+      const int j0 = FIRST ? j * R : ((j >> LNS) << (LNS + LR)) + (j & (NS - 1));
+      wbase[q] = IM::idx(j0);
+    }
+#pragma unroll
+    for (int q = 0; q < NB1; q++) rbase[q] = IM::idx((tid + q * T) & ((1 << LNR1) - 1));
+    float2 w[PL::E];
+    if constexpr (!FIRST) __syncthreads();  // the previous exchange's last reads are done
+#pragma unroll
+    for (int q = 0; q < NB; q++)
+#pragma unroll
+      for (int r = 0; r < R; r++) ldsf[wbase[q] + IM::delta(FIRST ? r : (r << LNS))] = v[q * R + r].x;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NB1; q++)
+#pragma unroll
+      for (int r = 0; r < R1; r++) w[q * R1 + r].x = ldsf[rbase[q] + IM::delta(r << LNR1)];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NB; q++)
+#pragma unroll
+      for (int r = 0; r < R; r++) ldsf[wbase[q] + IM::delta(FIRST ? r : (r << LNS))] = v[q * R + r].y;
+    // next pass's twiddle bases w^(2^i), w = W_N^stepk (TwPow::preload_pass): fetched once the outgoing data have left the registers
+    // (v is dead here: the loads cost no extra registers), in flight across the last barrier and the imaginary-part reads
+    constexpr int LNS1 = PL::lns(P + 1), NS1 = 1 << LNS1;
+    float2 nb[NB1 * LR1];
+#pragma unroll
+    for (int q = 0; q < NB1; q++) {
+      const int j = (tid + q * T) & ((1 << LNR1) - 1);
+      const int stepk = (j & (NS1 - 1)) << (LOGN - LNS1 - LR1);
+#pragma unroll
+      for (int i = 0; i < LR1; i++) nb[q * LR1 + i] = tw[stepk << i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NB1; q++)
+#pragma unroll
+      for (int r = 0; r < R1; r++) w[q * R1 + r].y = ldsf[rbase[q] + IM::delta(r << LNR1)];
+#pragma unroll
+    for (int i = 0; i < PL::E; i++) v[i] = w[i];
+    fft_split_passes<PL, P + 1, NESTED8, NESTED16>(v, ldsf, tw, nb, tid, st);
+  }
+}
+
+// v[16] = the thread's first-pass inputs (see Preloaded); ldsf = SplitImage<PL>::ELEMS floats; tw = table of N entries
+template <class PL, bool NESTED8, bool NESTED16 = false, class Store>
+__device__ __forceinline__ void fft_block_split(float2 *v, float *ldsf, const float2 *__restrict__ tw, int tid, Store st)
+{
+  fft_split_passes<PL, 0, NESTED8, NESTED16>(v, ldsf, tw, nullptr, tid, st);
 }
 
 }  // namespace armfft

@@ -217,10 +217,75 @@ static void add_o2(std::vector<A> &arms, const float2 *tw, uint32_t batch, int l
   arms.push_back({nm, [=](float2 *p) { k<<<batch, (1 << LOGN) / 16, lds_kb * 1024>>>(p, tw, batch); }, {}, 0});
 }
 
+
+// O3: one-shot kernel for 8192 / 16384 points with the half-footprint (re / im) exchange of fft_core_f32.hpp
+template <int LOGN, int MINW, bool NESTED8, int AUX, bool NESTED16 = false>
+__global__ __launch_bounds__((1 << LOGN) / 16, MINW) void o3_kernel(float2 *__restrict__ data, const float2 *__restrict__ tw, uint32_t batch)
+{
+  using PL = Plan<LOGN, (1 << LOGN) / 16>;
+  extern __shared__ __attribute__((aligned(16))) float2 lds[];
+  const int tid = threadIdx.x;
+  const uint32_t g0 = blockIdx.x;
+  const __amdgpu_buffer_rsrc_t rs = transform_rsrc(data + (size_t)g0 * PL::N, PL::N * 8u);
+  float2 v[16];
+  for_each_first_pass_input_split<PL>(tid, [&](int slot, int, int j, int roff) {
+    const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(rs, j * 8, roff * 8, AUX);
+    v[slot] = make_float2(__uint_as_float(w[0]), __uint_as_float(w[1]));
+  });
+  BufferStore<LOGN, false, 0, AUX> st{rs, 1.0f};
+  fft_block_split<PL, NESTED8, NESTED16>(v, reinterpret_cast<float *>(lds), tw, tid, st);
+}
+
+template <class A, int LOGN, int MINW, bool NESTED8, int AUX, bool NESTED16 = false>
+static void add_o3(std::vector<A> &arms, const float2 *tw, uint32_t batch, int lds_kb)
+{
+  auto k = o3_kernel<LOGN, MINW, NESTED8, AUX, NESTED16>;
+  CK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  char nm[96];
+  snprintf(nm, sizeof nm, "O3 split-exchange minw%d nested8 %d nested16 %d aux%d lds %d KiB", MINW, (int)NESTED8, (int)NESTED16, AUX, lds_kb);
+  arms.push_back({nm, [=](float2 *p) { k<<<batch, (1 << LOGN) / 16, lds_kb * 1024>>>(p, tw, batch); }, {}, 0});
+}
+
 template <class A>
 static void add_variants(std::vector<A> &arms, int logn, const float2 *tw, uint32_t batch)
 {
+  if (logn == 11) {
+    add_o3<A, 11, 4, false, 2>(arms, tw, batch, 9);
+    add_o3<A, 11, 4, true, 2>(arms, tw, batch, 9);
+    add_o3<A, 11, 4, false, 2>(arms, tw, batch, 12);
+    add_o3<A, 11, 4, false, 2>(arms, tw, batch, 18);
+    add_o3<A, 11, 4, false, 0>(arms, tw, batch, 9);
+  }
+  if (logn == 10) {
+    add_o3<A, 10, 4, false, 2>(arms, tw, batch, 5);
+    add_o3<A, 10, 4, true, 2>(arms, tw, batch, 5);
+    add_o3<A, 10, 4, false, 2>(arms, tw, batch, 8);
+    add_o3<A, 10, 4, false, 0>(arms, tw, batch, 5);
+  }
+  if (logn == 14) {
+    add_o3<A, 14, 8, true, 2>(arms, tw, batch, 70);
+    add_o3<A, 14, 8, false, 2>(arms, tw, batch, 70);
+    add_o3<A, 14, 8, true, 2, true>(arms, tw, batch, 70);
+    add_o3<A, 14, 8, false, 2, true>(arms, tw, batch, 70);
+    add_o3<A, 14, 8, true, 0, true>(arms, tw, batch, 70);
+  }
+  if (logn == 13) {
+    add_o3<A, 13, 4, true, 2>(arms, tw, batch, 36);
+    add_o3<A, 13, 4, false, 2>(arms, tw, batch, 36);
+    add_o3<A, 13, 6, false, 2>(arms, tw, batch, 36);
+    add_o3<A, 13, 8, false, 2>(arms, tw, batch, 36);
+    add_o3<A, 13, 8, true, 2>(arms, tw, batch, 36);
+    add_o3<A, 13, 4, false, 2>(arms, tw, batch, 50);
+  }
   if (logn == 12) {
+    add_o3<A, 12, 4, false, 2>(arms, tw, batch, 18);
+    add_o3<A, 12, 7, false, 2>(arms, tw, batch, 18);
+    add_o3<A, 12, 4, false, 2>(arms, tw, batch, 22);
+    add_o3<A, 12, 4, false, 2>(arms, tw, batch, 26);
+    add_o3<A, 12, 4, false, 2>(arms, tw, batch, 32);
+    add_o3<A, 12, 4, false, 2, true>(arms, tw, batch, 18);
+    add_o3<A, 12, 4, false, 0>(arms, tw, batch, 18);
+    add_o3<A, 12, 5, false, 2>(arms, tw, batch, 18);
     auto k = cfft_f32_kernel<12, false>;
     CK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     for (int kb : {76}) {
@@ -228,12 +293,5 @@ static void add_variants(std::vector<A> &arms, int logn, const float2 *tw, uint3
       snprintf(nm, sizeof nm, "library kernel, lds %d KiB (%d wg/cu)", kb, 160 / kb);
       arms.push_back({nm, [=](float2 *p) { k<<<batch, 256, kb * 1024>>>(p, tw, batch, batch, 0); }, {}, 0});
     }
-    add_o2<A, 12, 4, false, 2>(arms, tw, batch, 37);
-    add_o2<A, 12, 4, false, 2>(arms, tw, batch, 76);
-    add_o2<A, 12, 2, false, 2>(arms, tw, batch, 76);
-    add_o2<A, 12, 4, true, 2>(arms, tw, batch, 76);
-    add_o2<A, 12, 2, true, 2>(arms, tw, batch, 76);
-    add_o2<A, 12, 3, true, 2>(arms, tw, batch, 76);
-    add_o2<A, 12, 4, true, 2>(arms, tw, batch, 73);
   }
 }

@@ -72,13 +72,22 @@ int main()
 {
   CK(hipMalloc(&g_a, BYTES)); CK(hipMalloc(&g_b, BYTES));
   CK(hipMemset(g_a, 1, BYTES)); CK(hipMemset(g_b, 2, BYTES));
-  for (int lds_kb : {36, 72}) {
-    add<256, 8, 32768, 2, 2, true, 0>(lds_kb);
-    add<256, 8, 32768, 2, 2, true, 256>(lds_kb);
-    add<256, 8, 32768, 2, 2, true, 704>(lds_kb);
-    add<256, 8, 32768, 2, 2, true, 1408>(lds_kb);
-    add<256, 8, 32768, 2, 2, true, 2816>(lds_kb);
-  }
+  // 16384-point shape: one 128 KiB chunk per 1024-thread workgroup, 1 or 2 workgroups per CU, with a compute phase
+  add<1024, 8, 131072, 2, 2, true, 0>(144);
+  add<1024, 8, 131072, 2, 2, true, 2048>(144);
+  add<1024, 8, 131072, 2, 2, true, 4096>(144);
+  add<1024, 8, 131072, 2, 2, true, 0>(76);
+  add<1024, 8, 131072, 2, 2, true, 2048>(76);
+  add<1024, 8, 131072, 2, 2, true, 4096>(76);
+  add<1024, 8, 131072, 2, 2, true, 6144>(76);
+  // 8192-point shape: 64 KiB per 512-thread workgroup, 2 or 4 workgroups per CU
+  add<512, 8, 65536, 2, 2, true, 0>(76);
+  add<512, 8, 65536, 2, 2, true, 1536>(76);
+  add<512, 8, 65536, 2, 2, true, 3072>(76);
+  add<512, 8, 65536, 2, 2, true, 0>(38);
+  add<512, 8, 65536, 2, 2, true, 1536>(38);
+  add<512, 8, 65536, 2, 2, true, 3072>(38);
+  add<512, 8, 65536, 2, 2, true, 4096>(38);
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (int i = 0; i < 20; i++) g_cfgs[0].launch();   // clocks
   const int rounds = 9, reps = 4;

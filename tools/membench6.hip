@@ -62,6 +62,38 @@ __global__ __launch_bounds__(256) void reg_chunk_kernel(unsigned *__restrict__ d
   for (int i = 0; i < 16; i++) { v[i][0] += 1; __builtin_amdgcn_raw_buffer_store_b64(v[i], rs, threadIdx.x * 8, i * 2048, AUX); }
 }
 
+
+// register-path loaders: LW waves load (32/LW KiB each, 8 B per lane) and pass the chunk through LDS; SW waves store.
+// LW = 16, SW = 4: many loaders that exit early; LW = 4, SW = 16: few loaders, many storers (all alive to the end)
+template <int LW, int SW, int AUX>
+__global__ __launch_bounds__((LW > SW ? LW : SW) * 64) void split_chunk_kernel(unsigned *__restrict__ data)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned lds[];
+  constexpr int CH = 32768;
+  const size_t c = blockIdx.x;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)((char *)data + c * CH), 0, CH, 0x00020000);
+  const int wave = threadIdx.x >> 6;
+  const int tid = threadIdx.x;
+  if (wave < LW) {
+    constexpr int PER = 4096 / (LW * 64);   // 8-byte elements per thread
+    u32x2 v[PER];
+#pragma unroll
+    for (int i = 0; i < PER; i++) v[i] = __builtin_amdgcn_raw_buffer_load_b64(rs, tid * 8, i * LW * 512, AUX);
+#pragma unroll
+    for (int i = 0; i < PER; i++) *reinterpret_cast<u32x2 *>(lds + (tid + i * LW * 64) * 2) = v[i];
+  }
+  __syncthreads();
+  if (wave >= SW) return;
+  {
+    constexpr int PER = 4096 / (SW * 64);
+    u32x2 v[PER];
+#pragma unroll
+    for (int i = 0; i < PER; i++) v[i] = *reinterpret_cast<const u32x2 *>(lds + (tid + i * SW * 64) * 2);
+#pragma unroll
+    for (int i = 0; i < PER; i++) { v[i][0] += 1; __builtin_amdgcn_raw_buffer_store_b64(v[i], rs, tid * 8, i * SW * 512, AUX); }
+  }
+}
+
 static unsigned *g_a;
 static const size_t BYTES = 2ull << 30;
 struct Cfg { std::string name; std::function<void()> launch; std::vector<float> ms; };
@@ -77,6 +109,16 @@ static void add(int lds_kb)
   g_cfgs.push_back({buf, [=] { k<<<(unsigned)(BYTES / 32768), LW * 64, lds_kb * 1024>>>(g_a); }, {}});
 }
 
+template <int LW, int SW>
+static void add_split(int lds_kb)
+{
+  auto k = split_chunk_kernel<LW, SW, 2>;
+  CK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  char buf[160];
+  snprintf(buf, sizeof buf, "split: %2d load waves, %2d store waves, lds %3d KiB", LW, SW, lds_kb);
+  g_cfgs.push_back({buf, [=] { k<<<(unsigned)(BYTES / 32768), (LW > SW ? LW : SW) * 64, lds_kb * 1024>>>(g_a); }, {}});
+}
+
 int main()
 {
   CK(hipMalloc(&g_a, BYTES));
@@ -87,14 +129,13 @@ int main()
     CK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     g_cfgs.push_back({"register path T256 nt lds 76", [=] { k<<<(unsigned)(BYTES / 32768), 256, 76 * 1024>>>(g_a); }, {}});
   }
-  for (int lds_kb : {36, 76}) {
-    add<4, 2, 2, 8>(lds_kb);
-    add<4, 0, 2, 8>(lds_kb);
-    add<8, 2, 2, 8>(lds_kb);
-    add<16, 2, 2, 8>(lds_kb);
-    add<4, 2, 2, 16>(lds_kb);
-    add<8, 2, 2, 16>(lds_kb);
-    add<16, 2, 2, 16>(lds_kb);
+  for (int lds_kb : {36, 52, 76}) {
+    add_split<4, 4>(lds_kb);
+    add_split<16, 4>(lds_kb);
+    add_split<4, 16>(lds_kb);
+    add_split<16, 16>(lds_kb);
+    add_split<8, 4>(lds_kb);
+    add_split<8, 8>(lds_kb);
   }
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (int i = 0; i < 20; i++) g_cfgs[0].launch();
