@@ -479,6 +479,212 @@ __global__ __launch_bounds__(FixedPlan<LOGN>::T, 4) void cfft_fixed_kernel(typen
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Direct form (N = 4^k from 1024 points, bit-reversed output): the first step takes its 16 points straight from global
+// memory into registers (point tid + c*N/16: every load instruction is one contiguous run across the workgroup) and the
+// last step stores its 16 results straight to global memory -- thread tid transforms the 16-point block brev(tid) there,
+// so result c lands at index brev4(c)*N/16 + tid, contiguous across the lanes again.  Against cfft_fixed_kernel that is
+// half the LDS traffic (two of four round trips at 4096 points), two barriers fewer, and no address arithmetic for the
+// staging copies; the stages, their order and every rounding step are the same functions (bfly, StageKind).
+// LDS image: point p at word p + (p >> (LOGN-5)).  The last step reads blocks 2^(LOGN-5) points apart across 32 lanes:
+// that stride becomes odd; the first step's contiguous runs stay contiguous; the middle steps pick which (blk, j) bits
+// the low five lane bits carry so that their 32 lanes cover 32 banks too (dlane_map).  All offsets inside a step are
+// compile-time constants (doff).
+// ------------------------------------------------------------------------------------------
+template <int LOGN>
+struct DirectPlan {
+  static_assert((LOGN & 1) == 0 && LOGN >= 10, "direct form: N = 4^k, N >= 1024");
+  static constexpr int N = 1 << LOGN, T = N / 16, LOGT = LOGN - 4, M = LOGN / 2, SH = LOGN - 5;
+  static constexpr int LDS_WORDS = N + (N >> SH);
+  static __device__ __forceinline__ int pad(int p) { return p + (p >> SH); }
+  // offset of point e0 + (c << LOGQ) from pad(e0): exact whenever those points stay inside one aligned block of
+  // 2^(LOGQ+4) points that e0 starts with a remainder below 2^LOGQ (see the steps)
+  static constexpr int doff(int c, int logq) { return (c << logq) + ((c << logq) >> SH); }
+};
+
+// (blk, j) of thread tid in a middle step over blocks of 2^LOGN1 points (j < 2^(LOGN1-4)): any bijection is allowed, the
+// step is in place per thread.  The word address is (blk << LOGN1) + j + const + its own >> SH, so lane bit k (k < 5) is
+// given to the (blk, j) bit that moves bank bit k: j bit k directly, blk bit i through the pad term at bank bit
+// LOGN1 - SH + i.
+template <int LOGN, int LOGN1>
+__device__ __forceinline__ void dlane_map(int tid, int &blk, int &j)
+{
+  constexpr int LOGQ = LOGN1 - 4, SH = LOGN - 5, NB = LOGN - LOGN1, B0 = LOGN1 - SH;
+  if constexpr (LOGQ >= 5 || NB == 0) {
+    j = tid & ((1 << LOGQ) - 1);
+    blk = tid >> LOGQ;
+  } else if constexpr (B0 > 0) {
+    static_assert(B0 + NB == 5 && B0 <= LOGQ, "lane bits 0..4 = j bits 0..B0-1, then every blk bit");
+    j = (tid & ((1 << B0) - 1)) | ((tid >> 5) << B0);
+    blk = (tid >> B0) & ((1 << NB) - 1);
+  } else {
+    constexpr int HB = 5 - LOGQ;  // top HB bits of blk from lane bits LOGQ..4
+    static_assert(HB <= NB, "lane bits 0..4 = every j bit, then the top blk bits");
+    j = tid & ((1 << LOGQ) - 1);
+    blk = (((tid >> LOGQ) & ((1 << HB) - 1)) << (NB - HB)) | (tid >> 5);
+  }
+}
+
+// two fused stages S, S+1 on the 16 points x[c] = point e0 + (c << LOGQ) of a block of 2^LOGN1 = 2^(LOGL - 2S) points;
+// j = e0's offset inside the block's first sixteenth.  TWS(ic) / TWS1(ic) fetch table entry ic for the two stages.
+template <class Q, int LOGL, int S, bool INV, class TWS, class TWS1>
+__device__ __forceinline__ void pair_butterflies(typename Q::cpx *x, int j, TWS tws, TWS1 tws1)
+{
+  using cpx = typename Q::cpx;
+  constexpr int M = LOGL / 2, LOGQ = LOGL - 2 * S - 4;
+  constexpr int MOD_S = 1 << (2 * S), MOD_S1 = 1 << (2 * (S + 1));
+#pragma unroll
+  for (int b = 0; b < 4; b++) {
+    cpx y[4] = {x[b], x[4 + b], x[8 + b], x[12 + b]};
+    const int ic = (j + (b << LOGQ)) * MOD_S;
+    cpx w1{}, w2{}, w3{};
+    if (StageKind<S, M>::value != 2) {
+      w1 = Q::unpack(tws(ic));
+      w2 = Q::unpack(tws(2 * ic));
+      w3 = Q::unpack(tws(3 * ic));
+    }
+    bfly<Q, StageKind<S, M>::value, INV>(y, w1, w2, w3);
+    x[b] = y[0]; x[4 + b] = y[1]; x[8 + b] = y[2]; x[12 + b] = y[3];
+  }
+  cpx w1{}, w2{}, w3{};
+  if (StageKind<S + 1, M>::value != 2) {
+    const int ic = j * MOD_S1;
+    w1 = Q::unpack(tws1(ic));
+    w2 = Q::unpack(tws1(2 * ic));
+    w3 = Q::unpack(tws1(3 * ic));
+  }
+#pragma unroll
+  for (int a = 0; a < 4; a++) bfly<Q, StageKind<S + 1, M>::value, INV>(&x[4 * a], w1, w2, w3);
+}
+
+// middle steps S, S+1 (in place in LDS) up to, not including, the last pair
+template <class Q, int LOGN, int S, bool INV>
+__device__ __forceinline__ void direct_middle(typename Q::word *lds, const typename Q::tword *tl, int tid)
+{
+  using PL = DirectPlan<LOGN>;
+  using cpx = typename Q::cpx;
+  if constexpr (S < PL::M - 2) {
+    constexpr int LOGN1 = LOGN - 2 * S, LOGQ = LOGN1 - 4;
+    int blk, j;
+    dlane_map<LOGN, LOGN1>(tid, blk, j);
+    const int e0 = (blk << LOGN1) + j;
+    typename Q::word *base = lds + PL::pad(e0);
+    cpx x[16];
+#pragma unroll
+    for (int c = 0; c < 16; c++) x[c] = Q::unpack(base[PL::doff(c, LOGQ)]);
+    auto t4 = [&](int ic) { return tl[ic >> 2]; };
+    pair_butterflies<Q, LOGN, S, INV>(x, j, t4, t4);
+#pragma unroll
+    for (int c = 0; c < 16; c++) base[PL::doff(c, LOGQ)] = Q::pack(x[c]);
+    __syncthreads();
+    direct_middle<Q, LOGN, S + 2, INV>(lds, tl, tid);
+  }
+}
+
+template <class Q> struct DirectIo;
+template <> struct DirectIo<Q15> {
+  static __device__ __forceinline__ uint32_t load(const __amdgpu_buffer_rsrc_t &rs, int voff, int soff) { return __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 2); }
+  static __device__ __forceinline__ void store(uint32_t w, const __amdgpu_buffer_rsrc_t &rs, int voff, int soff) { __builtin_amdgcn_raw_buffer_store_b32(w, rs, voff, soff, 2); }
+};
+template <> struct DirectIo<Q31> {
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+  static __device__ __forceinline__ int2 load(const __amdgpu_buffer_rsrc_t &rs, int voff, int soff)
+  {
+    const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 2);
+    return make_int2((int)w[0], (int)w[1]);
+  }
+  static __device__ __forceinline__ void store(int2 v, const __amdgpu_buffer_rsrc_t &rs, int voff, int soff)
+  {
+    u32x2 w;
+    w[0] = (unsigned)v.x;
+    w[1] = (unsigned)v.y;
+    __builtin_amdgcn_raw_buffer_store_b64(w, rs, voff, soff, 2);
+  }
+};
+
+template <class Q, int LOGN, bool INV>
+__global__ __launch_bounds__(DirectPlan<LOGN>::T) void cfft_fixed_direct_kernel(typename Q::word *__restrict__ data,
+                                                                               const typename Q::tword *__restrict__ tw, uint32_t batch)
+{
+  using PL = DirectPlan<LOGN>;
+  using word = typename Q::word;
+  using tword = typename Q::tword;
+  using cpx = typename Q::cpx;
+  constexpr int W = sizeof(word), T = PL::T, M = PL::M;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  word *lds = reinterpret_cast<word *>(lds_raw);
+  tword *tl = reinterpret_cast<tword *>(lds + PL::LDS_WORDS);
+  const uint32_t g = blockIdx.x + blockIdx.y * gridDim.x;
+  if (g >= batch) return;
+  const int tid = threadIdx.x;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(data + (size_t)g * PL::N, 0, PL::N * W, 0x00020000);
+
+  // ---- first step: points tid + c*T from global memory ----
+  cpx x[16];
+#pragma unroll
+  for (int c = 0; c < 16; c++) x[c] = Q::unpack(DirectIo<Q>::load(rs, tid * W, c * T * W));
+  // every fourth table entry to LDS for the later stages (twidCoefModifier 4^S, S >= 1)
+  for (int i = tid; i < 3 * PL::N / 16; i += T) tl[i] = tw[4 * i];
+  auto tg = [&](int ic) { return tw[ic]; };
+  constexpr int S1 = (M & 1) ? 1 : 2;  // first stage of the middle steps
+  if constexpr ((M & 1) == 0) {
+    pair_butterflies<Q, LOGN, 0, INV>(x, tid, tg, tg);
+  } else {
+    // single stage 0: butterfly k over points u + a*N/4, u = tid + k*T (x[k + 4a])
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      cpx y[4] = {x[k], x[4 + k], x[8 + k], x[12 + k]};
+      const int ic = tid + k * T;
+      bfly<Q, 0, INV>(y, Q::unpack(tw[ic]), Q::unpack(tw[2 * ic]), Q::unpack(tw[3 * ic]));
+      x[k] = y[0]; x[4 + k] = y[1]; x[8 + k] = y[2]; x[12 + k] = y[3];
+    }
+  }
+  {
+    word *base = lds + PL::pad(tid);
+#pragma unroll
+    for (int c = 0; c < 16; c++) base[PL::doff(c, PL::LOGT)] = Q::pack(x[c]);
+  }
+  __syncthreads();
+
+  // ---- middle steps, in place in LDS ----
+  direct_middle<Q, LOGN, S1, INV>(lds, tl, tid);
+
+  // ---- last step: block brev(tid), results straight to global memory ----
+  {
+    const int blk = (int)(__brev((unsigned)tid) >> (32 - PL::LOGT));
+    const word *base = lds + PL::pad(blk << 4);
+#pragma unroll
+    for (int c = 0; c < 16; c++) x[c] = Q::unpack(base[c]);
+    // stage M-2 of the pair has the uniform twiddles b * 4^(M-2) (j = 0): scalar loads from the global table
+    pair_butterflies<Q, LOGN, M - 2, INV>(x, 0, tg, tg);
+#pragma unroll
+    for (int c = 0; c < 16; c++) {
+      const int rc = ((c & 1) << 3) | ((c & 2) << 1) | ((c & 4) >> 1) | ((c & 8) >> 3);
+      DirectIo<Q>::store(Q::pack(x[c]), rs, tid * W, rc * T * W);
+    }
+  }
+}
+
+template <class Q, int LOGN, bool INV>
+static hipError_t launch_fixed_direct(typename Q::word *data, const typename Q::tword *tw, uint32_t batch, hipStream_t stream)
+{
+  using PL = DirectPlan<LOGN>;
+  constexpr size_t lds_bytes = (size_t)PL::LDS_WORDS * sizeof(typename Q::word) + (size_t)(3 * PL::N / 16) * sizeof(typename Q::tword);
+  static_assert(lds_bytes <= 160 * 1024, "direct form: one transform and the quarter table in LDS");
+  static std::atomic<bool> attr_done[16];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  auto kern = cfft_fixed_direct_kernel<Q, LOGN, INV>;
+  if (lds_bytes > 48 * 1024 && (dev >= 16 || !attr_done[dev])) {
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+    if (dev < 16) attr_done[dev] = true;
+  }
+  const uint32_t gx = batch < 65536u ? batch : 65536u, gy = (batch + gx - 1) / gx;
+  kern<<<dim3(gx, gy, 1), PL::T, lds_bytes, stream>>>(data, tw, batch);
+  return hipGetLastError();
+}
+
 // ---- twiddle generation on the device (checked against the host table by the caller) ----
 template <typename T>
 __global__ void gen_twiddle_fixed_kernel(T *tw, uint32_t n, int rounding)
@@ -542,6 +748,14 @@ static hipError_t launch_fixed(int logn, typename Q::word *data, const typename 
                                hipStream_t stream)
 {
   if (batch == 0) return hipSuccess;
+  if (bitrev) {
+    switch (logn) {
+#define D(L) \
+  case L: return inverse ? launch_fixed_direct<Q, L, true>(data, tw, batch, stream) : launch_fixed_direct<Q, L, false>(data, tw, batch, stream);
+      D(10) D(12) D(14)
+#undef D
+    }
+  }
   switch (logn) {
 #define C(L) \
   case L: return inverse ? launch_fixed_one<Q, L, true>(data, tw, batch, bitrev, stream) : launch_fixed_one<Q, L, false>(data, tw, batch, bitrev, stream);
