@@ -8,14 +8,17 @@
 //   N = N1 * N2,  n = n1*N2 + n2,  k = k1 + N1*k2
 //   X[k1 + N1 k2] = sum_n2 W_N2^(n2 k2) * W_N^(n2 k1) * sum_n1 x[n1 N2 + n2] W_N1^(n1 k1)
 //
-// pass 1 (per tile of C adjacent columns n2): gather the N1 x C tile (C*8-byte runs) into LDS,
-//   N1-point FFT of every column in LDS, multiply by W_N^(n2 k1), write row n2 of the N2 x N1
-//   intermediate B[n2][k1] (fully coalesced) to the workspace;
-// pass 2 (per tile of C adjacent columns k1 of B): gather the N2 x C tile, N2-point FFTs, and
-//   scatter the tile to X[k1 + N1 k2] (C*8-byte runs).
+// pass 1 (per tile of C adjacent columns n2): the N1 x C tile (C*8-byte runs) straight into registers,
+//   N1-point FFT of every column, write row n2 of the N2 x N1 intermediate B[n2][k1] to the workspace
+//   (blocked layout from N = 2^17: see RowStore);
+// pass 2 (per tile of C adjacent columns k1 of B): the N2 x C tile into registers, times W_N^(n2 k1)
+//   (formed while the loads are in flight), N2-point FFTs, and straight to X[k1 + N1 k2] (C*8-byte runs).
 // Every point crosses HBM twice in each direction: 32*N bytes against the compulsory 16*N, so
-// the ceiling under SURVEY 8(d)'s accounting is 50 % of the HBM roofline; both are reported.
-// One workgroup = 1024 threads x 16 points = C sequences (C = 16384/N1), LDS 145 KiB.
+// the ceiling under SURVEY 8(d)'s accounting is 50 % of the HBM roofline; both are reported.  The tile
+// shapes themselves stream below the contiguous rate (tools/membench7, 8 x 2^22 points, no arithmetic:
+// contiguous copy 5.9 TB/s, pass 1's shape 4.6, pass 2's 4.8), which puts the two passes' floor at
+// 0.23 ms per 8 transforms = 0.29 of the roofline under 8(d).
+// One workgroup = 1024 threads x 16 points = C sequences (C = 16384/N1), 72 KiB of LDS, two per CU.
 #include <atomic>
 
 #include "armfft_internal.h"
@@ -25,9 +28,8 @@ namespace armfft {
 
 // Big twiddle W_N^m, m < N <= 2^22, as the product of three correctly rounded table entries,
 //   W_N^m = a[m & 127] * b[(m >> 7) & 127] * c[m >> 14]      (a: W_N^i, b: W_N^(128 i), c: W_N^(16384 i)),
-// 128 + 128 + 256 entries = 4 KiB, copied to LDS by every pass-1 workgroup: the lookups are LDS
-// reads (lgkmcnt), so nothing in the transform's store path touches vector memory and the
-// prefetch of the next tile survives until the loop top (see the kernel comment).  The table
+// 128 + 128 + 256 entries = 4 KiB, copied to LDS by every pass-2 workgroup: the lookups are LDS
+// reads, issued while the tile's global loads are still in flight.  The table
 // buffer keeps its historical size of 1 << kLoLog entries.
 constexpr int kLoLog = 10;
 constexpr int kBigA = 0, kBigB = 128, kBigC = 256, kBigEntries = 512;
@@ -52,10 +54,9 @@ __device__ __forceinline__ void buf_store(const __amdgpu_buffer_rsrc_t &rs, uint
   __builtin_amdgcn_raw_buffer_store_b64(w, rs, (int)voff, (int)soff, 0);
 }
 
-// MODE 1 store: output bin k = e0 + roff of sequence seq is multiplied by W_N^(seq k) and written
-// to the intermediate B[seq][k].  Layout of B: row-major (rows of 2^LOGA points), or -- `tiled` --
-// the order in which pass 2 consumes it: blocks of C2 = 16384 / n_seq adjacent columns k, each
-// block holding its rows one after the other ([k / C2][seq][k % C2], 16384 points = 128 KiB per
+// MODE 1 store: output bin k = e0 + roff of sequence seq goes to the intermediate B[seq][k].  Layout of B: row-major
+// (rows of 2^LOGA points), or -- `tiled` -- the order in which pass 2 consumes it: blocks of C2 = 16384 / n_seq adjacent
+// columns k, each block holding its rows one after the other ([k / C2][seq][k % C2], 16384 points = 128 KiB per
 // block).  Pass 2 then reads each of its tiles as ONE contiguous block instead of n_seq runs of
 // C2 * 8 = 64 bytes; this pass writes runs of C * C2 * 8 = 512 bytes instead of whole rows.  The
 // leg offset roff = r * Ns is a multiple of C2 whenever the launcher selects `tiled`, so it still
@@ -64,137 +65,146 @@ template <int LOGA, bool TILED>
 struct RowStore {
   static constexpr bool SPLIT = true;
   __amdgpu_buffer_rsrc_t rs;
-  const float2 *big;
   uint32_t c0;
   int log_seq;   // log2 of the number of sequences (rows of B)
   __device__ __forceinline__ void operator()(int t, int e0, int roff, float2 v) const
   {
     const uint32_t seq = c0 + (uint32_t)t;
-    const uint32_t m = seq * (uint32_t)(e0 + roff);  // < N
-    const float2 w = cmul(cmul(big[kBigA + (m & 127u)], big[kBigB + ((m >> 7) & 127u)]), big[kBigC + (m >> 14)]);
     const int lc2 = 14 - log_seq;
     const uint32_t row_major = (seq << LOGA) + (uint32_t)e0;
     const uint32_t blocked = (((uint32_t)e0 >> lc2) << 14) + (seq << lc2) + ((uint32_t)e0 & ((1u << lc2) - 1u));
     const uint32_t voff = (TILED ? blocked : row_major) * 8u;
     const uint32_t soff = (TILED ? (uint32_t)roff << log_seq : (uint32_t)roff) * 8u;
-    buf_store(rs, voff, soff, cmul(v, w));
+    buf_store(rs, voff, soff, v);
   }
 };
 
-// MODE 1: tile in -> FFT -> * W_N^(seq * k) -> rows out.   MODE 2: tile in -> FFT -> tile out.
-// Persistent workgroups, (a) XCD-aware: workgroups are dispatched round-robin over the 8 XCDs
-// (XCD = blockIdx % 8), each XCD has its own L2, and neighbouring column tiles share 128-byte lines
-// when C*8 = 64 (measured: 2x over-fetch when they are read at unrelated times/places).  So the
-// workgroups b and b + 8 -- same XCD, running side by side -- always work on the two tiles of one
-// pair (2q, 2q+1) in the same iteration: the second reader and the second writer of a line find it
-// in that XCD's L2.  (b) The next tile's 16 loads per thread are in flight (in registers) while
-// the current tile is transformed: with 145 KiB of LDS only one workgroup fits a CU, so without
-// this the memory system idles during every FFT.  gfx9 counts loads and stores in one in-order
-// vmcnt, so a prefetch survives only until the next wait on ANY later vector-memory access: the
-// loads are issued in the second-to-last pass (after its table twiddles have been consumed), the
-// last pass takes its twiddles from register-held powers (TwPow), the big twiddles of MODE 1 come
-// from LDS tables, nothing in the loop is conditional (the last round's
-// prefetch goes through an empty descriptor), and the waits the compiler derives are exact: at the loop top
-// vmcnt(#stores) -- loads landed, stores still draining.
+// One-shot tile kernel: one workgroup of 1024 threads per tile, two resident per CU (72 KiB of LDS, 64 VGPRs), so one
+// tile's loads and stores overlap the other's passes.  The A x C tile arrives in exactly the order the interleaved
+// split exchange wants (fft_core_f32.hpp, SplitImageIL: lane -> column first, then row), so the first pass takes its
+// inputs straight from the loads and the last pass stores straight to global memory: no staging copies, and the only
+// LDS traffic is the exchanges between passes (real parts, then imaginary parts).
+// MODE 1: tile of the input in -> FFT -> rows of the intermediate out.  Workgroups b and b + 8 -- same XCD, dispatched
+//   side by side -- take the two tiles that share 128-byte lines (`paired`): the second reader of a line finds it in that
+//   XCD's L2 (tools/membench7: strided reads 4.0 -> 4.6 TB/s with it; strided writes lose 8 %, so MODE 2 maps plainly).
+// MODE 2: tile of the intermediate in -> * W_N^(row * column) -> FFT -> tile of the output out.  The twiddles are formed
+//   from the LDS copy of the three-level table while the tile's loads are in flight.
+template <bool INV>
+struct TileStore {
+  static constexpr bool SPLIT = true;
+  __amdgpu_buffer_rsrc_t rs;
+  uint32_t other, c0;
+  float scale;
+  __device__ __forceinline__ void operator()(int t, int e0, int roff, float2 x) const
+  {
+    if (INV) x = make_float2(x.x * scale, -x.y * scale);
+    buf_store(rs, ((uint32_t)e0 * other + c0 + (uint32_t)t) * 8u, (uint32_t)roff * other * 8u, x);
+  }
+};
+
+#ifdef ARMFFT_LAB_STAMPS
+// lab builds only (tools/fourstep_lab.hip): per-workgroup phase time stamps, 8 x 64-bit words per workgroup
+__device__ unsigned long long *g_lab_stamps;
+#define LAB_STAMP(k) do { if (g_lab_stamps && threadIdx.x == 0) g_lab_stamps[(size_t)blockIdx.x * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define LAB_STAMP(k) do { } while (0)
+#endif
+
 template <int LOGA, int MODE, bool INV, bool TILED>
-__global__ __launch_bounds__(1024, 4) void fourstep_pass_kernel(const float2 *__restrict__ in, float2 *__restrict__ out,
+__global__ __launch_bounds__(1024, 8) void fourstep_tile_kernel(const float2 *__restrict__ in, float2 *__restrict__ out,
                                                                 const float2 *__restrict__ tw,      // 2^LOGA-point table
-                                                                const float2 *__restrict__ tw_big,  // three-level table of W_N (above)
-                                                                int log_other,                      // log2 of the other factor
-                                                                uint32_t tiles_per_xform, uint32_t n_items, int paired, float scale)
+                                                                const float2 *__restrict__ tw_big,  // three-level table of W_N
+                                                                int log_other, uint32_t tiles_per_xform, uint32_t n_items, int paired,
+                                                                float scale)
 {
   using PL = Plan<LOGA, 1024>;
-  constexpr int A = PL::N, C = PL::TPB, NP = PL::NPASS;
+  using IM = SplitImageIL<PL>;
+  constexpr int A = PL::N, C = PL::TPB, LOGC = IM::LOGC;
   static_assert(A * C == 16 * 1024, "16 points per thread");
-  static_assert(NP >= 2, "at least two passes");
-  constexpr int LAST = NP - 1, HP = NP - 2;
-  constexpr int LRL = PL::lr(LAST), RL = 1 << LRL, NBL = 16 / RL, LNSL = PL::lns(LAST), LNRL = LOGA - LRL;
-  extern __shared__ __attribute__((aligned(16))) float2 lds[];
-  const uint32_t other = 1u << log_other;  // row length of the matrix the tile is cut from
+  constexpr int R0 = 1 << PL::lr(0), NB0 = 16 / R0;
+  extern __shared__ __attribute__((aligned(16))) float ldsf[];
+  const uint32_t other = 1u << log_other;
   const size_t nfull = (size_t)A << log_other;
-  // item of iteration i for this workgroup (>= n_items: done)
-  uint32_t first, stride;
+  uint32_t item = blockIdx.x;
   if (paired) {
     const uint32_t x = blockIdx.x & 7u, s = blockIdx.x >> 3;   // XCD, slot on that XCD
-    first = 2u * ((s >> 1) * 8u + x) + (s & 1u);
-    stride = gridDim.x;                                          // = 2 * number of pair workers
-  } else {
-    first = blockIdx.x;
-    stride = gridDim.x;
+    item = 2u * ((s >> 1) * 8u + x) + (s & 1u);
   }
-  if (first >= n_items) return;
-
-  float2 *big = lds + PL::LDS_ELEMS;
-  if (MODE == 1) {
-    if (threadIdx.x < kBigEntries) big[threadIdx.x] = tw_big[threadIdx.x];
-  }
-  TwPow<PL, 1u << LAST, true> twp;
-  twp.preload(tw, threadIdx.x);
-
-  // element (row a, column c) of leg i: per-lane offset ((t / C) * other + tile * C + t % C) * 8 plus
-  // the scalar i * (1024 / C) * other * 8 (the same form serves the MODE 2 stores)
-  const uint32_t leg_step = (1024u / C) * other * 8u;
-  // MODE 2 reading a blocked intermediate: the tile is one contiguous block, leg i of thread t is
-  // element t + 1024 i of it
+  if (item >= n_items) return;
+  const int tid = threadIdx.x;
+  const uint32_t tile = item % tiles_per_xform, xf = item / tiles_per_xform;
+  const uint32_t c0 = tile * C;
+  LAB_STAMP(0);
+  // leg i of thread t: row t / C + i * 1024 / C, column c0 + t % C (or, from a blocked intermediate, element t + 1024 i of
+  // the tile's contiguous block: the same element); butterfly q, leg r of the first pass is leg i = q + r * NB0
+  float2 v[16];
+  const __amdgpu_buffer_rsrc_t rs = xform_rsrc(in + (size_t)xf * nfull, nfull);
   constexpr bool linear_in = (MODE == 2) && TILED;
-  const uint32_t in_step = linear_in ? 1024u * 8u : leg_step;
-  float2 pre[16];
-  auto issue = [&](uint32_t item, int t) {
-    // past the last item: a descriptor of zero bytes -- the loads stay in the instruction stream
-    // (no branch, exact waitcnt) but are out of range, return zero and fetch nothing
-    const bool live = item < n_items;
-    if (!live) item = 0;
-    const uint32_t tile = item % tiles_per_xform, xf = item / tiles_per_xform;
-    const __amdgpu_buffer_rsrc_t rs = xform_rsrc(in + (size_t)xf * nfull, live ? nfull : 0);
-    const uint32_t strided = ((uint32_t)t / C) * other + tile * C + (uint32_t)t % C;
-    const uint32_t voff = (linear_in ? (tile << 14) + (uint32_t)t : strided) * 8u;
+  const uint32_t voff = (linear_in ? (tile << 14) + (uint32_t)tid : ((uint32_t)tid >> LOGC) * other + c0 + ((uint32_t)tid & (C - 1))) * 8u;
+  const uint32_t step = linear_in ? 1024u * 8u : (1024u >> LOGC) * other * 8u;
 #pragma unroll
-    for (int i = 0; i < 16; i++) pre[i] = buf_load(rs, voff, i * in_step);
-  };
-  issue(first, threadIdx.x);
-  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the loop's waits derive from its back edge alone
-
-  for (uint32_t item = first; item < n_items; item += stride) {
-    int tid = threadIdx.x;
-    asm volatile("" : "+v"(tid));  // keep the per-thread address math inside the loop
-    twp.pin();
-    const uint32_t tile = item % tiles_per_xform, xf = item / tiles_per_xform;
-    const uint32_t c0 = tile * C;
-    const __amdgpu_buffer_rsrc_t ro = xform_rsrc(out + (size_t)xf * nfull, nfull);
-    // ---- stage the prefetched A x C tile: element (row a, column c0 + c) -> sequence c, point a ----
+  for (int i = 0; i < 16; i++) v[(i % NB0) * R0 + i / NB0] = buf_load(rs, voff, i * step);
+  LAB_STAMP(1);
+  if (MODE == 1) {
+    if (INV) {
+#pragma unroll
+      for (int i = 0; i < 16; i++) v[i].y = -v[i].y;  // inverse = conj(FFT(conj x)) / N
+    }
+  } else {
+    // B[row][col] *= W_N^(row * col): row = t / C + i * 1024 / C, col = c0 + t % C; the exponent advances by a constant
+    // per leg and stays below N
+    float2 *big = reinterpret_cast<float2 *>(ldsf + IM::ELEMS);
+    if (tid < kBigEntries) big[tid] = tw_big[tid];
+    __syncthreads();
+    const uint32_t col = c0 + ((uint32_t)tid & (C - 1));
+    uint32_t m = ((uint32_t)tid >> LOGC) * col;
+    const uint32_t dm = (1024u >> LOGC) * col;
 #pragma unroll
     for (int i = 0; i < 16; i++) {
-      const int v = tid + i * 1024, c = v % C, a = v / C;
-      float2 x = pre[i];
-      if (MODE == 1 && INV) x.y = -x.y;  // inverse = conj(FFT(conj x)) / N
-      lds[PL::idx(c, a)] = x;
+      const float2 w = cmul(cmul(big[kBigA + (m & 127u)], big[kBigB + ((m >> 7) & 127u)]), big[kBigC + (m >> 14)]);
+      float2 &x = v[(i % NB0) * R0 + i / NB0];
+      x = cmul(x, w);
+      m += dm;
     }
-    __syncthreads();
-    auto hook = [&]() { issue(item + stride, tid); };
-
-    auto ld = [&](int t, int e) -> float2 { return lds[PL::idx(t, e)]; };
-    if (MODE == 1) {
-      RowStore<LOGA, TILED> st{ro, big, c0, log_other};
-      fft_block_tw<PL, true, false, HP>(lds, twp, tid, ld, st, hook);
-    } else {
-      auto st = [&](int t, int k, float2 v) { lds[PL::idx(t, k)] = v; };
-      fft_block_tw<PL, true, true, HP>(lds, twp, tid, ld, st, hook);
-      __syncthreads();
-      // fresh opaque copy: the copy-out's address math must be computed here, not at the loop top
-      // (kept live across the transform it would spill, and a spill reload waits on vmcnt(0))
-      int tid2 = tid;
-      asm volatile("" : "+v"(tid2));
-      const uint32_t voff = (((uint32_t)tid2 / C) * other + c0 + (uint32_t)tid2 % C) * 8u;
-#pragma unroll
-      for (int i = 0; i < 16; i++) {
-        const int v = tid2 + i * 1024, c = v % C, k2 = v / C;
-        float2 x = lds[PL::idx(c, k2)];
-        if (INV) x = make_float2(x.x * scale, -x.y * scale);
-        buf_store(ro, voff, i * leg_step, x);
-      }
-    }
-    __syncthreads();  // LDS is free for the next tile
   }
+  LAB_STAMP(2);
+  const __amdgpu_buffer_rsrc_t ro = xform_rsrc(out + (size_t)xf * nfull, nfull);
+  if (MODE == 1) {
+    RowStore<LOGA, TILED> st{ro, c0, log_other};
+    fft_block_split_il<PL, false, false>(v, ldsf, tw, tid, st);
+  } else {
+    TileStore<INV> st{ro, other, c0, scale};
+    fft_block_split_il<PL, false, false>(v, ldsf, tw, tid, st);
+  }
+#ifdef ARMFFT_LAB_STAMPS
+  LAB_STAMP(3);
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's stores written
+  LAB_STAMP(4);
+#endif
+}
+
+template <int LOGA, int MODE, bool INV, bool TILED>
+static hipError_t launch_pass(const float2 *in, float2 *out, const float2 *tw, const float2 *tw_big, int log_other, uint32_t batch,
+                              float scale, hipStream_t stream)
+{
+  using PL = Plan<LOGA, 1024>;
+  const size_t lds_bytes = SplitImageIL<PL>::LDS_BYTES + (MODE == 2 ? sizeof(float2) * kBigEntries : 0);
+  static std::atomic<bool> attr_done[16];  // zero-initialised; a racing second hipFuncSetAttribute is harmless
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  auto kern = fourstep_tile_kernel<LOGA, MODE, INV, TILED>;
+  if (dev >= 16 || !attr_done[dev]) {
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+    if (dev < 16) attr_done[dev] = true;
+  }
+  const uint32_t tiles = (1u << log_other) / PL::TPB;
+  const uint64_t n_items = (uint64_t)tiles * batch;
+  if (n_items > 0x7fffffffull) return hipErrorInvalidValue;
+  // pair mapping: whole pairs, and a grid that is a multiple of 16 (two slots on each of the 8 XCDs)
+  const int paired = (MODE == 1 && tiles % 2 == 0 && n_items % 16 == 0) ? 1 : 0;
+  kern<<<(uint32_t)n_items, 1024, lds_bytes, stream>>>(in, out, tw, tw_big, log_other, tiles, (uint32_t)n_items, paired, scale);
+  return hipGetLastError();
 }
 
 __global__ void gen_twiddle_lo_kernel(float2 *tw, int logn)
@@ -215,34 +225,6 @@ __global__ void gen_twiddle_lo_kernel(float2 *tw, int logn)
 hipError_t launch_gen_twiddle_lo(float2 *tw, int logn, hipStream_t stream)
 {
   gen_twiddle_lo_kernel<<<(1 << kLoLog) / 256, 256, 0, stream>>>(tw, logn);
-  return hipGetLastError();
-}
-
-template <int LOGA, int MODE, bool INV, bool TILED>
-static hipError_t launch_pass(const float2 *in, float2 *out, const float2 *tw, const float2 *tw_big, int log_other, uint32_t batch,
-                              float scale, hipStream_t stream)
-{
-  using PL = Plan<LOGA, 1024>;
-  const size_t lds_bytes = PL::LDS_BYTES + (MODE == 1 ? sizeof(float2) * kBigEntries : 0);
-  static std::atomic<bool> attr_done[16];  // zero-initialised; a racing second hipFuncSetAttribute is harmless
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  auto kern = fourstep_pass_kernel<LOGA, MODE, INV, TILED>;
-  if (dev < 16 && !attr_done[dev]) {
-    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) return e;
-    attr_done[dev] = true;
-  }
-  const uint32_t tiles = (1u << log_other) / PL::TPB;
-  const uint32_t n_items = tiles * batch;
-  int cus = 0;
-  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-  // one resident workgroup per CU (LDS-limited).  Paired mapping needs whole pairs and a grid
-  // that is a multiple of 16 (two slots on each of the 8 XCDs).
-  uint32_t grid = n_items < (uint32_t)cus ? n_items : (uint32_t)cus;
-  const int paired = (tiles % 2 == 0 && grid >= 16) ? 1 : 0;
-  if (paired) grid &= ~15u;
-  kern<<<grid, 1024, lds_bytes, stream>>>(in, out, tw, tw_big, log_other, tiles, n_items, paired, scale);
   return hipGetLastError();
 }
 

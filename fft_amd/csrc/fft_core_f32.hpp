@@ -545,14 +545,34 @@ struct SplitImage {
   static_assert(PL::TPB == 1, "split exchange: one transform per workgroup");
   static constexpr int ELEMS = PL::N + (PL::N >> 4);
   static constexpr size_t LDS_BYTES = (size_t)ELEMS * sizeof(float);
-  static __device__ __forceinline__ int idx(int e) { return e + (e >> 4); }
+  // butterfly w = tid + q*T of a pass with 2^LNR butterflies per transform: its sequence and its index in the sequence
+  static __device__ __forceinline__ int seq(int, int) { return 0; }
+  static __device__ __forceinline__ int bfly(int w, int lnr) { return w & ((1 << lnr) - 1); }
+  static __device__ __forceinline__ int idx(int, int e) { return e + (e >> 4); }
   static constexpr int delta(int c) { return c + (c >> 4); }  // c's set bits disjoint from e's (leg strides)
 };
 
-template <class PL, int P, bool NESTED8, bool NESTED16, class Store>
+// The same exchange for TPB sequences per workgroup held INTERLEAVED: butterfly w works on sequence w % TPB, so the lanes
+// of a wave walk across the sequences first -- the order in which a column tile of a row-major matrix arrives from
+// global memory (TPB adjacent columns = one contiguous run per row) and leaves for it.  A tile kernel can therefore load
+// the first pass's inputs and store the last pass's outputs directly, with no staging copy through LDS.  Point e of
+// sequence t lives at float (e + (e >> 4)) * TPB + t: 32 lanes cover 32 / TPB consecutive or padded-apart points of TPB
+// adjacent sequences, conflict-free in every pass.
+template <class PL>
+struct SplitImageIL {
+  static constexpr int LOGC = __builtin_ctz(PL::TPB);
+  static_assert((1 << LOGC) == PL::TPB, "interleaved image: power-of-two sequences per workgroup");
+  static constexpr int ELEMS = (PL::N + (PL::N >> 4)) * PL::TPB;
+  static constexpr size_t LDS_BYTES = (size_t)ELEMS * sizeof(float);
+  static __device__ __forceinline__ int seq(int w, int) { return w & (PL::TPB - 1); }
+  static __device__ __forceinline__ int bfly(int w, int) { return w >> LOGC; }
+  static __device__ __forceinline__ int idx(int t, int e) { return ((e + (e >> 4)) << LOGC) + t; }
+  static constexpr int delta(int c) { return (c + (c >> 4)) << LOGC; }
+};
+
+template <class PL, class IM, int P, bool NESTED8, bool NESTED16, class Store>
 __device__ __forceinline__ void fft_split_passes(float2 *v, float *ldsf, const float2 *__restrict__ tw, const float2 *bases, int tid, Store &st)
 {
-  using IM = SplitImage<PL>;
   constexpr int LOGN = PL::LOGN, T = PL::T;
   constexpr int LR = PL::lr(P), R = 1 << LR, NB = PL::E / R;
   constexpr int LNS = PL::lns(P), NS = 1 << LNS;
@@ -567,12 +587,12 @@ __device__ __forceinline__ void fft_split_passes(float2 *v, float *ldsf, const f
   if constexpr (LAST) {
 #pragma unroll
     for (int q = 0; q < NB; q++) {
-      const int j = (tid + q * T) & ((1 << LNR) - 1);
+      const int t = IM::seq(tid + q * T, LNR), j = IM::bfly(tid + q * T, LNR);
       const int j0 = ((j >> LNS) << (LNS + LR)) + (j & (NS - 1));
 #pragma unroll
       for (int r = 0; r < R; r++) {
-        if constexpr (store_is_split<Store>::value) st(0, j0, r << LNS, v[q * R + r]);
-        else st(0, j0 + (r << LNS), v[q * R + r]);
+        if constexpr (store_is_split<Store>::value) st(t, j0, r << LNS, v[q * R + r]);
+        else st(t, j0 + (r << LNS), v[q * R + r]);
       }
     }
   } else {
@@ -581,12 +601,12 @@ __device__ __forceinline__ void fft_split_passes(float2 *v, float *ldsf, const f
     int wbase[NB], rbase[NB1];
 #pragma unroll
     for (int q = 0; q < NB; q++) {
-      const int j = (tid + q * T) & ((1 << LNR) - 1);
+      const int t = IM::seq(tid + q * T, LNR), j = IM::bfly(tid + q * T, LNR);
       const int j0 = FIRST ? j * R : ((j >> LNS) << (LNS + LR)) + (j & (NS - 1));
-      wbase[q] = IM::idx(j0);
+      wbase[q] = IM::idx(t, j0);
     }
 #pragma unroll
-    for (int q = 0; q < NB1; q++) rbase[q] = IM::idx((tid + q * T) & ((1 << LNR1) - 1));
+    for (int q = 0; q < NB1; q++) rbase[q] = IM::idx(IM::seq(tid + q * T, LNR1), IM::bfly(tid + q * T, LNR1));
     float2 w[PL::E];
     if constexpr (!FIRST) __syncthreads();  // the previous exchange's last reads are done
 #pragma unroll
@@ -609,7 +629,7 @@ __device__ __forceinline__ void fft_split_passes(float2 *v, float *ldsf, const f
     float2 nb[NB1 * LR1];
 #pragma unroll
     for (int q = 0; q < NB1; q++) {
-      const int j = (tid + q * T) & ((1 << LNR1) - 1);
+      const int j = IM::bfly(tid + q * T, LNR1);
       const int stepk = (j & (NS1 - 1)) << (LOGN - LNS1 - LR1);
 #pragma unroll
       for (int i = 0; i < LR1; i++) nb[q * LR1 + i] = tw[stepk << i];
@@ -621,7 +641,7 @@ __device__ __forceinline__ void fft_split_passes(float2 *v, float *ldsf, const f
       for (int r = 0; r < R1; r++) w[q * R1 + r].y = ldsf[rbase[q] + IM::delta(r << LNR1)];
 #pragma unroll
     for (int i = 0; i < PL::E; i++) v[i] = w[i];
-    fft_split_passes<PL, P + 1, NESTED8, NESTED16>(v, ldsf, tw, nb, tid, st);
+    fft_split_passes<PL, IM, P + 1, NESTED8, NESTED16>(v, ldsf, tw, nb, tid, st);
   }
 }
 
@@ -629,7 +649,15 @@ __device__ __forceinline__ void fft_split_passes(float2 *v, float *ldsf, const f
 template <class PL, bool NESTED8, bool NESTED16 = false, class Store>
 __device__ __forceinline__ void fft_block_split(float2 *v, float *ldsf, const float2 *__restrict__ tw, int tid, Store st)
 {
-  fft_split_passes<PL, 0, NESTED8, NESTED16>(v, ldsf, tw, nullptr, tid, st);
+  fft_split_passes<PL, SplitImage<PL>, 0, NESTED8, NESTED16>(v, ldsf, tw, nullptr, tid, st);
+}
+
+// Interleaved sequences (SplitImageIL): v[q*R + r] = point bfly + r * N/R of sequence (tid + q*T) % TPB, bfly = (tid + q*T) / TPB;
+// ldsf = SplitImageIL<PL>::ELEMS floats
+template <class PL, bool NESTED8, bool NESTED16 = false, class Store>
+__device__ __forceinline__ void fft_block_split_il(float2 *v, float *ldsf, const float2 *__restrict__ tw, int tid, Store st)
+{
+  fft_split_passes<PL, SplitImageIL<PL>, 0, NESTED8, NESTED16>(v, ldsf, tw, nullptr, tid, st);
 }
 
 }  // namespace armfft
