@@ -102,14 +102,6 @@ struct TileStore {
   }
 };
 
-#ifdef ARMFFT_LAB_STAMPS
-// lab builds only (tools/fourstep_lab.hip): per-workgroup phase time stamps, 8 x 64-bit words per workgroup
-__device__ unsigned long long *g_lab_stamps;
-#define LAB_STAMP(k) do { if (g_lab_stamps && threadIdx.x == 0) g_lab_stamps[(size_t)blockIdx.x * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
-#else
-#define LAB_STAMP(k) do { } while (0)
-#endif
-
 template <int LOGA, int MODE, bool INV, bool TILED>
 __global__ __launch_bounds__(1024, 8) void fourstep_tile_kernel(const float2 *__restrict__ in, float2 *__restrict__ out,
                                                                 const float2 *__restrict__ tw,      // 2^LOGA-point table
@@ -134,7 +126,6 @@ __global__ __launch_bounds__(1024, 8) void fourstep_tile_kernel(const float2 *__
   const int tid = threadIdx.x;
   const uint32_t tile = item % tiles_per_xform, xf = item / tiles_per_xform;
   const uint32_t c0 = tile * C;
-  LAB_STAMP(0);
   // leg i of thread t: row t / C + i * 1024 / C, column c0 + t % C (or, from a blocked intermediate, element t + 1024 i of
   // the tile's contiguous block: the same element); butterfly q, leg r of the first pass is leg i = q + r * NB0
   float2 v[16];
@@ -144,7 +135,12 @@ __global__ __launch_bounds__(1024, 8) void fourstep_tile_kernel(const float2 *__
   const uint32_t step = linear_in ? 1024u * 8u : (1024u >> LOGC) * other * 8u;
 #pragma unroll
   for (int i = 0; i < 16; i++) v[(i % NB0) * R0 + i / NB0] = buf_load(rs, voff, i * step);
-  LAB_STAMP(1);
+  // The passes' twiddle bases are entries below A/2 of the A-point table: an LDS copy, so that no pass waits for a
+  // global load queued behind the other resident workgroup's tile traffic (first read after the first exchange's barriers)
+  float2 *big = reinterpret_cast<float2 *>(ldsf + IM::ELEMS);
+  float2 *twl = big + (MODE == 2 ? kBigEntries : 0);
+  static_assert(A / 2 <= 1024, "one table entry per thread");
+  if (tid < A / 2) twl[tid] = tw[tid];
   if (MODE == 1) {
     if (INV) {
 #pragma unroll
@@ -153,7 +149,6 @@ __global__ __launch_bounds__(1024, 8) void fourstep_tile_kernel(const float2 *__
   } else {
     // B[row][col] *= W_N^(row * col): row = t / C + i * 1024 / C, col = c0 + t % C; the exponent advances by a constant
     // per leg and stays below N
-    float2 *big = reinterpret_cast<float2 *>(ldsf + IM::ELEMS);
     if (tid < kBigEntries) big[tid] = tw_big[tid];
     __syncthreads();
     const uint32_t col = c0 + ((uint32_t)tid & (C - 1));
@@ -167,20 +162,14 @@ __global__ __launch_bounds__(1024, 8) void fourstep_tile_kernel(const float2 *__
       m += dm;
     }
   }
-  LAB_STAMP(2);
   const __amdgpu_buffer_rsrc_t ro = xform_rsrc(out + (size_t)xf * nfull, nfull);
   if (MODE == 1) {
     RowStore<LOGA, TILED> st{ro, c0, log_other};
-    fft_block_split_il<PL, false, false>(v, ldsf, tw, tid, st);
+    fft_block_split_il<PL, true, true>(v, ldsf, twl, tid, st);
   } else {
     TileStore<INV> st{ro, other, c0, scale};
-    fft_block_split_il<PL, false, false>(v, ldsf, tw, tid, st);
+    fft_block_split_il<PL, true, true>(v, ldsf, twl, tid, st);
   }
-#ifdef ARMFFT_LAB_STAMPS
-  LAB_STAMP(3);
-  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's stores written
-  LAB_STAMP(4);
-#endif
 }
 
 template <int LOGA, int MODE, bool INV, bool TILED>
@@ -188,7 +177,7 @@ static hipError_t launch_pass(const float2 *in, float2 *out, const float2 *tw, c
                               float scale, hipStream_t stream)
 {
   using PL = Plan<LOGA, 1024>;
-  const size_t lds_bytes = SplitImageIL<PL>::LDS_BYTES + (MODE == 2 ? sizeof(float2) * kBigEntries : 0);
+  const size_t lds_bytes = SplitImageIL<PL>::LDS_BYTES + sizeof(float2) * ((MODE == 2 ? kBigEntries : 0) + PL::N / 2);
   static std::atomic<bool> attr_done[16];  // zero-initialised; a racing second hipFuncSetAttribute is harmless
   int dev = 0;
   (void)hipGetDevice(&dev);
