@@ -242,9 +242,11 @@ __device__ __forceinline__ Cand cand_better(Cand a, Cand b)
   return take_b ? b : a;
 }
 
+// LDS scratch of top2_scan for T threads: per wave a prefix-maximum total, a lower bound, a candidate and a double sum
+constexpr size_t top2_scratch_bytes(int T) { return (size_t)((T + 63) / 64) * 32 + 16; }
+
 // T threads, thread tid owns samples [tid*CH, tid*CH + CH) of mag(m) (m < n valid; FULL: n == T*CH).
-// `xch` = LDS scratch of >= 3 * (T/64) * 8 + 16 bytes not aliased with what mag() reads.  All
-// threads return the result.
+// `xch` = LDS scratch of top2_scratch_bytes(T) bytes not aliased with what mag() reads.  All threads return the result.
 template <int T, int CH, bool FULL, class Mag>
 __device__ __forceinline__ Top2 top2_scan(Mag mag, int n, int sep, int tid, void *xch)
 {
@@ -252,7 +254,7 @@ __device__ __forceinline__ Top2 top2_scan(Mag mag, int n, int sep, int tid, void
   const int lane = tid & 63, wv = tid >> 6;
   const int m0 = tid * CH;
   float x[CH];
-  PrefixMax loc{kNoPeak, -1}, prevloc{kNoPeak, -1};  // chunk maximum (last index on ties) and the chunk's state just before it
+  PrefixMax loc{kNoPeak, -1};  // chunk maximum (last index on ties)
   float fsum = 0.f;
 #pragma unroll
   for (int c = 0; c < CH; c++) {
@@ -261,8 +263,6 @@ __device__ __forceinline__ Top2 top2_scan(Mag mag, int n, int sep, int tid, void
     x[c] = ok ? mag(m) : kNoPeak;
     fsum += ok ? x[c] : 0.f;
     const bool rec = ok && x[c] >= loc.v;
-    prevloc.v = rec ? loc.v : prevloc.v;
-    prevloc.i = rec ? loc.i : prevloc.i;
     loc.v = rec ? x[c] : loc.v;
     loc.i = rec ? m : loc.i;
   }
@@ -283,6 +283,7 @@ __device__ __forceinline__ Top2 top2_scan(Mag mag, int n, int sep, int tid, void
   PrefixMax *wtot = reinterpret_cast<PrefixMax *>(xch);   // [NW]
   Cand *wcand = reinterpret_cast<Cand *>(wtot + NW);       // [NW]
   double *wsum = reinterpret_cast<double *>(wcand + NW);   // [NW]
+  float *wlow = reinterpret_cast<float *>(wsum + NW);      // [NW]
   if (lane == 63) wtot[wv] = inc;
   __syncthreads();
   PrefixMax before{kNoPeak, -1}, total{kNoPeak, -1};
@@ -306,38 +307,46 @@ __device__ __forceinline__ Top2 top2_scan(Mag mag, int n, int sep, int tid, void
     if (!(ok && far)) k.ord = 0u;
     return k;
   };
-  // Round 1: only the chunk maximum of every thread offers (its state = the thread's incoming state
-  // advanced over the chunk's earlier samples = prevloc).  The best of these over the WAVE is a real
-  // candidate, so its value L is a lower bound of the final runner-up: a sample below L cannot win
-  // -- as a (B) candidate its value is its own, as an (A) candidate it hands down a record that is
-  // not larger than itself -- and equal values still take part (>=).
-  Cand best = offer(loc.v, loc.i, loc.i != -1, pm_combine(run, prevloc));
-  // (butterfly inside the rows by DPP -- cand_better is a maximum over distinct keys, so any
-  // pairing works --, the two cross-row steps through the LDS crossbar)
-  auto wave_best = [](Cand k) -> Cand {
+  // Lower bound L of the runner-up: a chunk that starts more than sep after the maximum's position i1 sees the final
+  // state (v1, i1) at every sample, none of its samples is a record (the maximum keeps the LAST index on ties), so its
+  // own maximum is a real (B) candidate.  L = the largest of these over the workgroup (none: no bound).  A sample below L
+  // cannot win -- as a (B) candidate its value is its own, as an (A) candidate it hands down a record that is not
+  // larger than itself -- and equal values still take part (>=).
+  float low = (loc.i != -1 && m0 > total.i + sep) ? loc.v : -__builtin_huge_valf();
+  low = fmaxf(low, dpp_f<kDppXor1>(low, low));
+  low = fmaxf(low, dpp_f<kDppXor2>(low, low));
+  low = fmaxf(low, dpp_f<kDppHalfMirror>(low, low));
+  low = fmaxf(low, dpp_f<kDppMirror>(low, low));
+  low = fmaxf(low, __shfl_xor(low, 16));
+  low = fmaxf(low, __shfl_xor(low, 32));
+  if (lane == 0) wlow[wv] = low;
+  __syncthreads();
+  float lower = wlow[0];
+#pragma unroll
+  for (int w = 1; w < NW; w++) lower = fmaxf(lower, wlow[w]);
+  // Walk the chunk: the state advances at every sample (3 operations), the offer is evaluated only in steps where some
+  // lane of the wave holds a sample >= L; a wave none of whose chunk maxima reaches L skips the walk -- for a noise
+  // row that leaves a handful of steps in one or two waves.
+  Cand best{0.f, 0u};
+  if (__any(loc.v >= lower)) {
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+      const int m = m0 + c;
+      const bool ok = FULL || m < n;
+      if (__any(ok && x[c] >= lower)) best = cand_better(best, offer(x[c], m, ok, run));
+      const bool rec = ok && x[c] >= run.v;
+      run.v = rec ? x[c] : run.v;
+      run.i = rec ? m : run.i;
+    }
+    // (butterfly inside the rows by DPP -- cand_better is a maximum over distinct keys, so any
+    // pairing works --, the two cross-row steps through the LDS crossbar)
 #define ARMFFT_RED_STEP(CTRL)                                                                                        \
-  k = cand_better(k, Cand{dpp_f<CTRL>(k.v, k.v), (unsigned)dpp_i<CTRL>((int)k.ord, (int)k.ord)});
+  best = cand_better(best, Cand{dpp_f<CTRL>(best.v, best.v), (unsigned)dpp_i<CTRL>((int)best.ord, (int)best.ord)});
     ARMFFT_RED_STEP(kDppXor1) ARMFFT_RED_STEP(kDppXor2) ARMFFT_RED_STEP(kDppHalfMirror) ARMFFT_RED_STEP(kDppMirror)
 #undef ARMFFT_RED_STEP
-    k = cand_better(k, Cand{__shfl_xor(k.v, 16), __shfl_xor(k.ord, 16)});
-    k = cand_better(k, Cand{__shfl_xor(k.v, 32), __shfl_xor(k.ord, 32)});
-    return k;
-  };
-  const Cand wbest = wave_best(best);
-  const float lower = wbest.ord ? wbest.v : -__builtin_huge_valf();
-  // Round 2: walk the chunk; the state advances at every sample (3 operations), the offer is
-  // evaluated only in steps where some lane of the wave holds a sample >= L -- for a noise row
-  // that is a handful of the 16 steps of one or two waves.
-#pragma unroll
-  for (int c = 0; c < CH; c++) {
-    const int m = m0 + c;
-    const bool ok = FULL || m < n;
-    if (__any(ok && x[c] >= lower)) best = cand_better(best, offer(x[c], m, ok, run));
-    const bool rec = ok && x[c] >= run.v;
-    run.v = rec ? x[c] : run.v;
-    run.i = rec ? m : run.i;
+    best = cand_better(best, Cand{__shfl_xor(best.v, 16), __shfl_xor(best.ord, 16)});
+    best = cand_better(best, Cand{__shfl_xor(best.v, 32), __shfl_xor(best.ord, 32)});
   }
-  best = wave_best(best);
   {
     auto dsum_step = [&](auto mover) {
       const long long bits = __double_as_longlong(sum);
@@ -405,7 +414,7 @@ __device__ __forceinline__ void finish_row(const Top2 &t, Mag mag, int n, int do
 template <bool CPLX>
 __global__ __launch_bounds__(256) void gnss_top2_kernel(const float *__restrict__ data, int n, int sep, gnss_top2 *__restrict__ out)
 {
-  __shared__ __attribute__((aligned(16))) unsigned char xch[3 * 4 * 8 + 16];
+  __shared__ __attribute__((aligned(16))) unsigned char xch[top2_scratch_bytes(256)];
   const float *row = data + (size_t)blockIdx.x * n * (CPLX ? 2 : 1);
   auto mag = [&](int m) -> float {
     if (CPLX) {
@@ -557,7 +566,7 @@ __global__ __launch_bounds__(GPlan<LOGN>::T, GPlan<LOGN>::T >= 1024 ? 4 : 3) voi
   // LDS map: [0, LDS_ELEMS) FFT image (the magnitude row aliases its head), then the exchange
   // scratch of top2_scan, then the per-block phasors w[b]
   unsigned char *xch = reinterpret_cast<unsigned char *>(lds + PL::LDS_ELEMS);
-  float2 *wblk = reinterpret_cast<float2 *>(xch + 3 * ((T + 63) / 64) * 8 + 16);
+  float2 *wblk = reinterpret_cast<float2 *>(xch + top2_scratch_bytes(T));
   float *magl = reinterpret_cast<float *>(lds);
   auto mag_idx = [](int m) { return m + ((m >> 4) << 2); };  // 16 floats + 4 pad: conflict-free 16-byte chunk reads
 
@@ -599,7 +608,8 @@ __global__ __launch_bounds__(GPlan<LOGN>::T, GPlan<LOGN>::T >= 1024 ? 4 : 3) voi
       const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(cs, j * 8, roff * 8, 0);
       v[slot] = cmul(zc[slot], make_float2(__uint_as_float(w[0]), __uint_as_float(w[1])));
     });
-    auto st = [&](int, int k, float2 y) { magl[mag_idx(k)] = sqrtf(y.x * y.x + y.y * y.y); };
+    // (v_sqrt_f32: 1 ulp, no denormal rescue -- the magnitudes are O(1) after the 1/N scaling above)
+    auto st = [&](int, int k, float2 y) { magl[mag_idx(k)] = __builtin_amdgcn_sqrtf(y.x * y.x + y.y * y.y); };
     fft_block_preloaded<PL, true>(v, lds, twp, lt, st);
     __syncthreads();
     auto mag = [&](int m) -> float { return magl[mag_idx(m)]; };
@@ -766,7 +776,7 @@ hipError_t launch_acquire(const gnss_acq_plan *pl, const void *sig, int packed, 
                           hipStream_t s)
 {
   using PL = GPlan<LOGN>;
-  const size_t lds = PL::LDS_BYTES + 3 * ((PL::T + 63) / 64) * 8 + 16 + kMaxMs * sizeof(float2);
+  const size_t lds = PL::LDS_BYTES + top2_scratch_bytes(PL::T) + kMaxMs * sizeof(float2);
   auto k = gnss_acquire_kernel<LOGN>;
   static std::atomic<bool> done[16];
   hipError_t e = lds_attr_once(k, lds, done, pl->device);
@@ -782,7 +792,7 @@ hipError_t launch_groups(const gnss_acq_plan *pl, const void *sig, int packed, u
 {
   using PL = GPlan<LOGN>;
   const size_t lds_a = PL::LDS_BYTES + kMaxMs * sizeof(float2);
-  const size_t lds_b = PL::LDS_BYTES + 3 * ((PL::T + 63) / 64) * 8 + 16;
+  const size_t lds_b = PL::LDS_BYTES + top2_scratch_bytes(PL::T);
   auto ka = gnss_group_spectra_kernel<LOGN>;
   static std::atomic<bool> done_a[16], done_b1[16], done_b2[16];
   hipError_t e = lds_attr_once(ka, lds_a, done_a, pl->device);
