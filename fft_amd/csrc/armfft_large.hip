@@ -165,10 +165,10 @@ __global__ __launch_bounds__(1024, 8) void fourstep_tile_kernel(const float2 *__
   const __amdgpu_buffer_rsrc_t ro = xform_rsrc(out + (size_t)xf * nfull, nfull);
   if (MODE == 1) {
     RowStore<LOGA, TILED> st{ro, c0, log_other};
-    fft_block_split_il<PL, true, true>(v, ldsf, twl, tid, st);
+    fft_block_split_il<PL, true, true, true>(v, ldsf, twl, tid, st);
   } else {
     TileStore<INV> st{ro, other, c0, scale};
-    fft_block_split_il<PL, true, true>(v, ldsf, twl, tid, st);
+    fft_block_split_il<PL, true, true, true>(v, ldsf, twl, tid, st);
   }
 }
 

@@ -10,7 +10,7 @@ for spec in "$@"; do
   WL=${spec%%:*}; FLT=${spec##*:}
   for C in FETCH_SIZE WRITE_SIZE; do
     D=$ROOT/gpurun_out/tr_$C; rm -rf "$D"
-    timeout -s KILL 120 rocprofv3 --pmc $C --output-format csv -d "$D" -- python3 bench.py --no-cpu-baseline --workload "$WL" --steps 2 --warmup 1 > "$D.log" 2>&1 || { echo "$WL $C failed"; tail -3 "$D.log"; exit 1; }
+    timeout -s KILL 120 rocprofv3 --pmc $C --output-format csv -d "$D" -- python3 bench.py --no-cpu-baseline --no-extra --workload "$WL" --steps 2 --warmup 1 > "$D.log" 2>&1 || { echo "$WL $C failed"; tail -3 "$D.log"; exit 1; }
     python3 tools/summarize_prof.py "$D" "$D.txt" "$FLT" > /dev/null
     awk -v wl="$WL" -v c="$C" '$0 !~ /^#/ && $0 !~ /^kernel/ { n=NF; printf "%s %s %s calls=%s avg_per_dispatch=%s\n", wl, c, $(n-4), $(n-2), $(n-1) }' "$D.txt" | sed 's/ [^ ]*<\([^>]*\)>[^ ]* / <\1> /' >> "$OUT"
     rm -rf "$D" "$D.log" "$D.txt"
