@@ -18,104 +18,161 @@
 
 namespace armfft {
 
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ float2 cmul(float2 a, float2 w)
-{
-  return make_float2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x);
-}
-__device__ __forceinline__ float2 cmul_conj(float2 a, float2 w)  // a * conj(w)
-{
-  return make_float2(a.x * w.x + a.y * w.y, a.y * w.x - a.x * w.y);
-}
-__device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }   // * (-i)
+// ---- complex arithmetic ----
+// Two spellings of the same operations, chosen per plan (Plan::AR):
+//   ArPk: packed fp32 (v_pk_*_f32: one instruction works on the (re, im) register pair).  The compiler forms packed
+//         adds by itself but not the half-swapped, half-negated operand forms that complex multiplication and rotation
+//         by -i need (it falls back to scalar instructions plus register moves), so those are spelled out: op_sel /
+//         op_sel_hi pick which half of each source feeds the low / high lane, neg_lo / neg_hi negate there.  Half the
+//         VALU instructions of the scalar form and ~20 fewer registers: the compute-bound GNSS kernel, the real FFTs
+//         and most complex sizes gain (same-box A/B: GNSS 3.84 -> 3.50 ms, rfft 16384 0.62 -> 0.65 of the roofline,
+//         cfft 1024 0.74 -> 0.77, 16384 0.68 -> 0.69);
+//   ArSc: plain C++ on the components, scheduled freely by the compiler: the 4096- and 8192-point one-shot kernels
+//         stream 5-7 % faster with it (0.749 against 0.681 of the roofline at 4096, whatever the workgroups per CU).
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f tov(float2 a) { return __builtin_bit_cast(v2f, a); }
+__device__ __forceinline__ float2 tof(v2f a) { return __builtin_bit_cast(float2, a); }
+
+struct ArPk {
+  static __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return tof(tov(a) + tov(b)); }
+  static __device__ __forceinline__ float2 csub(float2 a, float2 b) { return tof(tov(a) - tov(b)); }
+  // a + (-i) b = (a.x + b.y, a.y - b.x)
+  static __device__ __forceinline__ float2 cadd_mi(float2 a, float2 b)
+  {
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(tov(a)), "v"(tov(b)));
+    return tof(r);
+  }
+  // a - (-i) b = (a.x - b.y, a.y + b.x)
+  static __device__ __forceinline__ float2 csub_mi(float2 a, float2 b)
+  {
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(tov(a)), "v"(tov(b)));
+    return tof(r);
+  }
+  static __device__ __forceinline__ float2 cmul(float2 a, float2 w)
+  {
+    // t = (a.y w.y, a.y w.x);  r = (a.x w.x - t.x, a.x w.y + t.y)
+    v2f t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(tov(a)), "v"(tov(w)));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] neg_lo:[0,0,1]" : "=v"(r) : "v"(tov(a)), "v"(tov(w)), "v"(t));
+    return tof(r);
+  }
+  static __device__ __forceinline__ float2 cmul_conj(float2 a, float2 w)  // a * conj(w) = (a.x w.x + a.y w.y, a.y w.x - a.x w.y)
+  {
+    v2f t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(tov(a)), "v"(tov(w)));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(tov(a)), "v"(tov(w)), "v"(t));
+    return tof(r);
+  }
+  static __device__ __forceinline__ float2 mul_mi(float2 a)   // * (-i) = (a.y, -a.x)
+  {
+    v2f r;
+    asm("v_pk_mul_f32 %0, %1, 1.0 op_sel:[1,0] op_sel_hi:[0,0] neg_hi:[1,0]" : "=v"(r) : "v"(tov(a)));
+    return tof(r);
+  }
+  // e + c * s for a real constant c
+  static __device__ __forceinline__ float2 cfma_r(float2 s, float c, float2 e)
+  {
+    const v2f cc = {c, c};
+    return tof(__builtin_elementwise_fma(tov(s), cc, tov(e)));
+  }
+  static __device__ __forceinline__ float2 scale(float2 a, float c)
+  {
+    const v2f cc = {c, c};
+    return tof(tov(a) * cc);
+  }
+};
+
+struct ArSc {
+  static __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+  static __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+  static __device__ __forceinline__ float2 cadd_mi(float2 a, float2 b) { return make_float2(a.x + b.y, a.y - b.x); }
+  static __device__ __forceinline__ float2 csub_mi(float2 a, float2 b) { return make_float2(a.x - b.y, a.y + b.x); }
+  static __device__ __forceinline__ float2 cmul(float2 a, float2 w) { return make_float2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x); }
+  static __device__ __forceinline__ float2 cmul_conj(float2 a, float2 w) { return make_float2(a.x * w.x + a.y * w.y, a.y * w.x - a.x * w.y); }
+  static __device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }
+  static __device__ __forceinline__ float2 cfma_r(float2 s, float c, float2 e) { return make_float2(e.x + c * s.x, e.y + c * s.y); }
+  static __device__ __forceinline__ float2 scale(float2 a, float c) { return make_float2(a.x * c, a.y * c); }
+};
+
+// the kernels' own complex arithmetic (spectrum products, split / merge stages, big twiddles): packed
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return ArPk::cadd(a, b); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return ArPk::csub(a, b); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 w) { return ArPk::cmul(a, w); }
+__device__ __forceinline__ float2 cmul_conj(float2 a, float2 w) { return ArPk::cmul_conj(a, w); }
+__device__ __forceinline__ float2 mul_mi(float2 a) { return ArPk::mul_mi(a); }
 
 // ---- in-register butterflies: forward DFT, natural order in and out ----
-__device__ __forceinline__ void fft2(float2 &a, float2 &b)
-{
-  float2 t = a;
-  a = cadd(t, b);
-  b = csub(t, b);
-}
-
+template <class AR>
 __device__ __forceinline__ void fft4(float2 &a0, float2 &a1, float2 &a2, float2 &a3)
 {
-  float2 t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = mul_mi(csub(a1, a3));
-  a0 = cadd(t0, t2);
-  a1 = cadd(t1, t3);
-  a2 = csub(t0, t2);
-  a3 = csub(t1, t3);
+  const float2 t0 = AR::cadd(a0, a2), t1 = AR::csub(a0, a2), t2 = AR::cadd(a1, a3), d = AR::csub(a1, a3);
+  a0 = AR::cadd(t0, t2);
+  a1 = AR::cadd_mi(t1, d);
+  a2 = AR::csub(t0, t2);
+  a3 = AR::csub_mi(t1, d);
 }
 
-template <int R>
-__device__ __forceinline__ void butterfly(float2 *v);
-
-template <>
-__device__ __forceinline__ void butterfly<2>(float2 *v)
+template <int R, class AR = ArPk>
+__device__ __forceinline__ void butterfly(float2 *v)
 {
-  fft2(v[0], v[1]);
-}
-
-template <>
-__device__ __forceinline__ void butterfly<4>(float2 *v)
-{
-  fft4(v[0], v[1], v[2], v[3]);
-}
-
-template <>
-__device__ __forceinline__ void butterfly<8>(float2 *v)
-{
-  const float c = 0.70710678118654752440f;
-  fft4(v[0], v[2], v[4], v[6]);  // E0..E3
-  fft4(v[1], v[3], v[5], v[7]);  // O0..O3
-  float2 o1 = make_float2(c * (v[3].x + v[3].y), c * (v[3].y - v[3].x));   // * W8^1
-  float2 o2 = mul_mi(v[5]);                                                // * W8^2
-  float2 o3 = make_float2(c * (v[7].y - v[7].x), -c * (v[7].x + v[7].y));  // * W8^3
-  float2 e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6], o0 = v[1];
-  v[0] = cadd(e0, o0);
-  v[4] = csub(e0, o0);
-  v[1] = cadd(e1, o1);
-  v[5] = csub(e1, o1);
-  v[2] = cadd(e2, o2);
-  v[6] = csub(e2, o2);
-  v[3] = cadd(e3, o3);
-  v[7] = csub(e3, o3);
-}
-
-template <>
-__device__ __forceinline__ void butterfly<16>(float2 *v)
-{
-  // 16 = 4 x 4: X[q1 + 4 q2] = sum_b W16^(b q1) W4^(b q2) sum_a v[4a + b] W4^(a q1)
-  const float c8 = 0.70710678118654752440f;
-  const float c16 = 0.92387953251128675613f, s16 = 0.38268343236508977173f;
+  static_assert(R == 2 || R == 4 || R == 8 || R == 16, "radix");
+  if constexpr (R == 2) {
+    const float2 t = v[0];
+    v[0] = AR::cadd(t, v[1]);
+    v[1] = AR::csub(t, v[1]);
+  } else if constexpr (R == 4) {
+    fft4<AR>(v[0], v[1], v[2], v[3]);
+  } else if constexpr (R == 8) {
+    const float c = 0.70710678118654752440f;
+    fft4<AR>(v[0], v[2], v[4], v[6]);  // E0..E3
+    fft4<AR>(v[1], v[3], v[5], v[7]);  // O0..O3
+    // O1 W8^1 = c (x + y, y - x) = c * s1;  O2 W8^2 = -i O2;  O3 W8^3 = -c (x - y, x + y) = -c * s3
+    const float2 s1 = AR::cadd_mi(v[3], v[3]), s3 = AR::csub_mi(v[7], v[7]);
+    const float2 e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6], o0 = v[1], o2 = v[5];
+    v[0] = AR::cadd(e0, o0);
+    v[4] = AR::csub(e0, o0);
+    v[1] = AR::cfma_r(s1, c, e1);
+    v[5] = AR::cfma_r(s1, -c, e1);
+    v[2] = AR::cadd_mi(e2, o2);
+    v[6] = AR::csub_mi(e2, o2);
+    v[3] = AR::cfma_r(s3, -c, e3);
+    v[7] = AR::cfma_r(s3, c, e3);
+  } else {
+    // 16 = 4 x 4: X[q1 + 4 q2] = sum_b W16^(b q1) W4^(b q2) sum_a v[4a + b] W4^(a q1)
+    const float c8 = 0.70710678118654752440f;
+    const float c16 = 0.92387953251128675613f, s16 = 0.38268343236508977173f;
 #pragma unroll
-  for (int b = 0; b < 4; b++) fft4(v[b], v[4 + b], v[8 + b], v[12 + b]);  // v[4 q1 + b] = u_b[q1]
-  // twiddle u_b[q1] by W16^(b q1)
-  v[4 * 1 + 1] = cmul(v[4 * 1 + 1], make_float2(c16, -s16));                                             // W16^1
-  v[4 * 1 + 2] = make_float2(c8 * (v[4 * 1 + 2].x + v[4 * 1 + 2].y), c8 * (v[4 * 1 + 2].y - v[4 * 1 + 2].x));  // W16^2
-  v[4 * 1 + 3] = cmul(v[4 * 1 + 3], make_float2(s16, -c16));                                             // W16^3
-  v[4 * 2 + 1] = make_float2(c8 * (v[4 * 2 + 1].x + v[4 * 2 + 1].y), c8 * (v[4 * 2 + 1].y - v[4 * 2 + 1].x));  // W16^2
-  v[4 * 2 + 2] = mul_mi(v[4 * 2 + 2]);                                                                   // W16^4
-  v[4 * 2 + 3] = make_float2(c8 * (v[4 * 2 + 3].y - v[4 * 2 + 3].x), -c8 * (v[4 * 2 + 3].x + v[4 * 2 + 3].y)); // W16^6
-  v[4 * 3 + 1] = cmul(v[4 * 3 + 1], make_float2(s16, -c16));                                             // W16^3
-  v[4 * 3 + 2] = make_float2(c8 * (v[4 * 3 + 2].y - v[4 * 3 + 2].x), -c8 * (v[4 * 3 + 2].x + v[4 * 3 + 2].y)); // W16^6
-  v[4 * 3 + 3] = cmul(v[4 * 3 + 3], make_float2(-c16, s16));                                             // W16^9
-  // second layer over b; result X[q1 + 4 q2] lands in v[4 q1 + q2] -> transpose to natural order
+    for (int b = 0; b < 4; b++) fft4<AR>(v[b], v[4 + b], v[8 + b], v[12 + b]);  // v[4 q1 + b] = u_b[q1]
+    // twiddle u_b[q1] by W16^(b q1)
+    v[4 * 1 + 1] = AR::cmul(v[4 * 1 + 1], make_float2(c16, -s16));               // W16^1
+    v[4 * 1 + 2] = AR::scale(AR::cadd_mi(v[4 * 1 + 2], v[4 * 1 + 2]), c8);       // W16^2 = c8 (x + y, y - x)
+    v[4 * 1 + 3] = AR::cmul(v[4 * 1 + 3], make_float2(s16, -c16));               // W16^3
+    v[4 * 2 + 1] = AR::scale(AR::cadd_mi(v[4 * 2 + 1], v[4 * 2 + 1]), c8);       // W16^2
+    v[4 * 2 + 2] = AR::mul_mi(v[4 * 2 + 2]);                                     // W16^4
+    v[4 * 2 + 3] = AR::scale(AR::csub_mi(v[4 * 2 + 3], v[4 * 2 + 3]), -c8);      // W16^6 = -c8 (x - y, x + y)
+    v[4 * 3 + 1] = AR::cmul(v[4 * 3 + 1], make_float2(s16, -c16));               // W16^3
+    v[4 * 3 + 2] = AR::scale(AR::csub_mi(v[4 * 3 + 2], v[4 * 3 + 2]), -c8);      // W16^6
+    v[4 * 3 + 3] = AR::cmul(v[4 * 3 + 3], make_float2(-c16, s16));               // W16^9
+    // second layer over b; result X[q1 + 4 q2] lands in v[4 q1 + q2] -> transpose to natural order
 #pragma unroll
-  for (int q1 = 0; q1 < 4; q1++) fft4(v[4 * q1 + 0], v[4 * q1 + 1], v[4 * q1 + 2], v[4 * q1 + 3]);
-  float2 t;
+    for (int q1 = 0; q1 < 4; q1++) fft4<AR>(v[4 * q1 + 0], v[4 * q1 + 1], v[4 * q1 + 2], v[4 * q1 + 3]);
+    float2 t;
 #define ARMFFT_SWAP(i, j) t = v[i]; v[i] = v[j]; v[j] = t;
-  ARMFFT_SWAP(1, 4) ARMFFT_SWAP(2, 8) ARMFFT_SWAP(3, 12) ARMFFT_SWAP(6, 9) ARMFFT_SWAP(7, 13) ARMFFT_SWAP(11, 14)
+    ARMFFT_SWAP(1, 4) ARMFFT_SWAP(2, 8) ARMFFT_SWAP(3, 12) ARMFFT_SWAP(6, 9) ARMFFT_SWAP(7, 13) ARMFFT_SWAP(11, 14)
 #undef ARMFFT_SWAP
+  }
 }
 
 // ---- compile-time plan ----
-// Plan<LOGN, TT, PP>: TT threads per workgroup (0 = default: 256 below 4096 points, N/16 above).
+// Plan<LOGN, TT, PP, PK>: TT threads per workgroup (0 = default: 256 below 4096 points, N/16 above).
 // PP: two LDS images used alternately (pass p writes image p & 1), which removes the barrier between
 // a middle pass's reads and its writes -- for kernels that run few workgroups per CU and have the
 // LDS to spare.
-template <int LOGN_, int TT = 0, bool PP = false>
+template <int LOGN_, int TT = 0, bool PP = false, bool PK = true>
 struct Plan {
+  using AR = typename std::conditional<PK, ArPk, ArSc>::type;  // complex arithmetic of the passes (see ArPk / ArSc)
   static constexpr bool PINGPONG = PP;
   static constexpr int E = 16;  // points per thread and pass
   static constexpr int LOGN = LOGN_;
@@ -254,9 +311,10 @@ struct TwRegs {
 // NESTED8 / NESTED16: radix-8 / radix-16 passes multiply the data by the bases directly (v5 = (v5 w1) w4 ...): a few more
 // complex multiplies (12 for 11, 32 for 26), the same number of roundings per leg or one more, and no product temporaries
 // at all -- for kernels at the edge of their register budget.
-template <int LR, bool NESTED8, bool NESTED16 = false>
+template <int LR, bool NESTED8, bool NESTED16 = false, class AR = ArPk>
 __device__ __forceinline__ void twpow_mul(const float2 *bq, float2 *v)
 {
+  auto cmul = [](float2 a, float2 w) { return AR::cmul(a, w); };
   if constexpr ((NESTED8 && LR == 3) || (NESTED16 && LR == 4)) {
 #pragma unroll
     for (int r = 1; r < (1 << LR); r++) {
@@ -361,7 +419,7 @@ struct TwPow {
   __device__ __forceinline__ void mul(int q, float2 *v) const
   {
     constexpr int LR = PL::lr(P);
-    twpow_mul<LR, NESTED8>(&b[P][q * nbase(LR)], v);
+    twpow_mul<LR, NESTED8, false, typename PL::AR>(&b[P][q * nbase(LR)], v);
   }
 };
 
@@ -433,7 +491,7 @@ __device__ __forceinline__ void fft_pass(float2 *v, float2 *lds, const TW &tw, i
         tw.template mul<P>(q, v + q * R);
       } else {
 #pragma unroll
-        for (int r = 1; r < R; r++) v[q * R + r] = cmul(v[q * R + r], twc[q * (R - 1) + r - 1]);
+        for (int r = 1; r < R; r++) v[q * R + r] = PL::AR::cmul(v[q * R + r], twc[q * (R - 1) + r - 1]);
       }
     }
   }
@@ -444,7 +502,7 @@ __device__ __forceinline__ void fft_pass(float2 *v, float2 *lds, const TW &tw, i
     __builtin_amdgcn_sched_barrier(0);
   }
 #pragma unroll
-  for (int q = 0; q < NB; q++) butterfly<R>(v + q * R);
+  for (int q = 0; q < NB; q++) butterfly<R, typename PL::AR>(v + q * R);
   // ---- scatter ----
   // source and destination both in LDS: every read of this pass must finish before any write
   if ((!FIRST || LDS_IN) && (!LAST || LDS_OUT) && !(PL::PINGPONG && !FIRST && !LAST)) __syncthreads();
@@ -589,14 +647,14 @@ __device__ __forceinline__ void fft_split_passes(float2 *v, float *ldsf, const f
         float2 bq[LR];
 #pragma unroll
         for (int i = 0; i < LR; i++) bq[i] = tw[stepk << i];
-        twpow_mul<LR, NESTED8, NESTED16>(bq, v + q * R);
+        twpow_mul<LR, NESTED8, NESTED16, typename PL::AR>(bq, v + q * R);
       } else {
-        twpow_mul<LR, NESTED8, NESTED16>(bases + q * LR, v + q * R);
+        twpow_mul<LR, NESTED8, NESTED16, typename PL::AR>(bases + q * LR, v + q * R);
       }
     }
   }
 #pragma unroll
-  for (int q = 0; q < NB; q++) butterfly<R>(v + q * R);
+  for (int q = 0; q < NB; q++) butterfly<R, typename PL::AR>(v + q * R);
   if constexpr (LAST) {
 #pragma unroll
     for (int q = 0; q < NB; q++) {
