@@ -79,8 +79,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // Plan of the complex kernel: one-shot sizes below 4096 points use N/16 threads (at least one
 // wave: 256 and 512 points put 4 / 2 transforms in it); the staged and plain kernels below 256
 // points use single-wave workgroups too.
-// (packed arithmetic everywhere but at 2048, 4096 and 8192 points: see ArPk / ArSc)
-template <int LOGN> using CPlan = Plan<LOGN, LOGN <= 7 ? 64 : (Tune<LOGN>::ONESHOT && LOGN < 12) ? ((1 << LOGN) / 16 < 64 ? 64 : (1 << LOGN) / 16) : 0, false, !(LOGN >= 11 && LOGN <= 13)>;
+// (packed arithmetic everywhere but at 128, 512, 2048, 4096 and 8192 points (same-box A/B per size): see ArPk / ArSc)
+template <int LOGN> using CPlan = Plan<LOGN, LOGN <= 7 ? 64 : (Tune<LOGN>::ONESHOT && LOGN < 12) ? ((1 << LOGN) / 16 < 64 ? 64 : (1 << LOGN) / 16) : 0, false, !(LOGN == 7 || LOGN == 9 || (LOGN >= 11 && LOGN <= 13))>;
 
 // Buffer descriptor over one transform (gfx9 raw buffer: stride 0, range in bytes, 32-bit data
 // format): address = base + scalar offset + per-lane offset, so the 16 legs of a thread share ONE
