@@ -62,6 +62,31 @@ BENCH(lshl_add_u32, A_LSHLADD)
 BENCH(bfe_i32, A_BFE)
 BENCH(alignbit_b32, A_ALIGNBIT)
 
+// packed fp32 on register pairs
+#define PKBENCH(NAME, INSTR)                                                                                   \
+  __global__ __launch_bounds__(256) void k_##NAME(int *out, long long *cyc, int seed)                         \
+  {                                                                                                           \
+    typedef float v2f __attribute__((ext_vector_type(2)));                                                    \
+    v2f a0 = {(float)seed, 1.f}, a1 = a0 * 3.f, a2 = a0 * 5.f, a3 = a0 * 7.f, a4 = a0 * 11.f, a5 = a0 * 13.f, a6 = a0 * 17.f, a7 = a0 * 19.f; \
+    v2f b = {1.0001f, 0.9999f}, c = {1e-9f, 2e-9f};                                                            \
+    const long long t0 = __builtin_readcyclecounter();                                                        \
+    for (int it = 0; it < 1024; it++) {                                                                       \
+      asm volatile(INSTR(0) INSTR(1) INSTR(2) INSTR(3) INSTR(4) INSTR(5) INSTR(6) INSTR(7) INSTR(0) INSTR(1) INSTR(2) INSTR(3) INSTR(4) INSTR(5) INSTR(6) INSTR(7) \
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)           \
+                   : "v"(b), "v"(c));                                                                         \
+    }                                                                                                         \
+    const long long t1 = __builtin_readcyclecounter();                                                        \
+    const v2f s = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;                                                       \
+    out[blockIdx.x * 256 + threadIdx.x] = (int)(s.x + s.y);                                                   \
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;                                                          \
+  }
+#define A_PKFMA32(i) "v_pk_fma_f32 %" #i ", %" #i ", %8, %9\n"
+#define A_PKADD32(i) "v_pk_add_f32 %" #i ", %" #i ", %8\n"
+#define A_PKMUL32(i) "v_pk_mul_f32 %" #i ", %" #i ", %8 op_sel:[1,1] op_sel_hi:[1,0]\n"
+PKBENCH(pk_fma_f32, A_PKFMA32)
+PKBENCH(pk_add_f32, A_PKADD32)
+PKBENCH(pk_mul_f32_opsel, A_PKMUL32)
+
 // 64-bit multiply-add: v_mad_i64_i32 (64-bit accumulator pair)
 __global__ __launch_bounds__(256) void k_mad_i64_i32(int *out, long long *cyc, int seed)
 {
@@ -105,7 +130,7 @@ int main()
   CK(hipMalloc(&out, 256 * 256 * 4)); CK(hipMalloc(&cyc, 256 * 8));
   for (int rep = 0; rep < 2; rep++) {
 #define R(n) run(#n, k_##n, out, cyc);
-    R(fma_f32) R(add_u32) R(add3_u32) R(ashrrev_i32) R(lshl_add_u32) R(bfe_i32) R(alignbit_b32) R(perm_b32)
+    R(pk_fma_f32) R(pk_add_f32) R(pk_mul_f32_opsel) R(fma_f32) R(add_u32) R(add3_u32) R(ashrrev_i32) R(lshl_add_u32) R(bfe_i32) R(alignbit_b32) R(perm_b32)
     R(mul_hi_i32) R(mul_lo_u32) R(mad_i64_i32) R(mad_i32_i24) R(mul_i32_i24) R(mul_hi_i32_i24) R(mad_i32_i16)
     R(dot2_i32_i16) R(pk_add_i16_clamp) R(pk_ashrrev_i16) R(pk_mul_lo_u16) R(pk_mad_i16)
   }
