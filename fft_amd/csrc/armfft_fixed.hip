@@ -480,7 +480,7 @@ __global__ __launch_bounds__(FixedPlan<LOGN>::T, 4) void cfft_fixed_kernel(typen
 }
 
 // ------------------------------------------------------------------------------------------
-// Direct form (N = 4^k from 1024 points, bit-reversed output): the first step takes its 16 points straight from global
+// Direct form (1024 ... 16384 points, bit-reversed output): the first step takes its 16 points straight from global
 // memory into registers (point tid + c*N/16: every load instruction is one contiguous run across the workgroup) and the
 // last step stores its 16 results straight to global memory -- thread tid transforms the 16-point block brev(tid) there,
 // so result c lands at index brev4(c)*N/16 + tid, contiguous across the lanes again.  Against cfft_fixed_kernel that is
@@ -490,11 +490,20 @@ __global__ __launch_bounds__(FixedPlan<LOGN>::T, 4) void cfft_fixed_kernel(typen
 // that stride becomes odd; the first step's contiguous runs stay contiguous; the middle steps pick which (blk, j) bits
 // the low five lane bits carry so that their 32 lanes cover 32 banks too (dlane_map).  All offsets inside a step are
 // compile-time constants (doff).
+// N = 2 * 4^k (2048, 8192): points c and c + 8 of a thread are N/2 apart, so the radix-2 pre-stage of
+// arm_cfft_radix4by2_* runs on the registers right after the loads, and points c, c+2, c+4, c+6 are a stage-0 butterfly of
+// the thread's half: the first step is pre-stage + stage 0 of both halves.  The two half-length transforms then share
+// the LDS image (blocks never straddle the halves), the twiddle modifier starts at 2, and the final << 1 goes into the
+// last step's stores.  An odd number of stages between the first step and the last pair (8192) runs one single-stage
+// step first.
 // ------------------------------------------------------------------------------------------
 template <int LOGN>
 struct DirectPlan {
-  static_assert((LOGN & 1) == 0 && LOGN >= 10, "direct form: N = 4^k, N >= 1024");
-  static constexpr int N = 1 << LOGN, T = N / 16, LOGT = LOGN - 4, M = LOGN / 2, SH = LOGN - 5;
+  static_assert(LOGN >= 10 && LOGN <= 14, "direct form: 1024 ... 16384 points");
+  static constexpr bool BY2 = (LOGN & 1) != 0;
+  static constexpr int LOGL = BY2 ? LOGN - 1 : LOGN;   // the radix-4 transforms' length
+  static constexpr int TWMOD0 = BY2 ? 2 : 1;           // their twidCoefModifier at stage 0
+  static constexpr int N = 1 << LOGN, T = N / 16, LOGT = LOGN - 4, M = LOGL / 2, SH = LOGN - 5;
   static constexpr int LDS_WORDS = N + (N >> SH);
   static __device__ __forceinline__ int pad(int p) { return p + (p >> SH); }
   // offset of point e0 + (c << LOGQ) from pad(e0): exact whenever those points stay inside one aligned block of
@@ -525,14 +534,15 @@ __device__ __forceinline__ void dlane_map(int tid, int &blk, int &j)
   }
 }
 
-// two fused stages S, S+1 on the 16 points x[c] = point e0 + (c << LOGQ) of a block of 2^LOGN1 = 2^(LOGL - 2S) points;
-// j = e0's offset inside the block's first sixteenth.  TWS(ic) / TWS1(ic) fetch table entry ic for the two stages.
-template <class Q, int LOGL, int S, bool INV, class TWS, class TWS1>
-__device__ __forceinline__ void pair_butterflies(typename Q::cpx *x, int j, TWS tws, TWS1 tws1)
+// Stage S on the 16 points x[c] = point e0 + (c << LOGQ) of a block of 2^LOGN1 = 2^(LOGL - 2S) points (LOGQ = LOGN1 - 4);
+// j = e0's offset inside the block's first sixteenth: butterfly b over x[b], x[4+b], x[8+b], x[12+b].  TWS(ic) fetches
+// table entry ic; TWMOD0 = the transform's twidCoefModifier at stage 0.
+template <class Q, int LOGL, int S, bool INV, int TWMOD0, class TWS>
+__device__ __forceinline__ void stage_butterflies(typename Q::cpx *x, int j, TWS tws)
 {
   using cpx = typename Q::cpx;
   constexpr int M = LOGL / 2, LOGQ = LOGL - 2 * S - 4;
-  constexpr int MOD_S = 1 << (2 * S), MOD_S1 = 1 << (2 * (S + 1));
+  constexpr int MOD_S = TWMOD0 << (2 * S);
 #pragma unroll
   for (int b = 0; b < 4; b++) {
     cpx y[4] = {x[b], x[4 + b], x[8 + b], x[12 + b]};
@@ -546,6 +556,16 @@ __device__ __forceinline__ void pair_butterflies(typename Q::cpx *x, int j, TWS 
     bfly<Q, StageKind<S, M>::value, INV>(y, w1, w2, w3);
     x[b] = y[0]; x[4 + b] = y[1]; x[8 + b] = y[2]; x[12 + b] = y[3];
   }
+}
+
+// two fused stages S, S+1 on the same 16 points: stage S as above, then stage S+1's butterfly a over x[4a .. 4a+3]
+template <class Q, int LOGL, int S, bool INV, int TWMOD0, class TWS, class TWS1>
+__device__ __forceinline__ void pair_butterflies(typename Q::cpx *x, int j, TWS tws, TWS1 tws1)
+{
+  using cpx = typename Q::cpx;
+  constexpr int M = LOGL / 2;
+  constexpr int MOD_S1 = TWMOD0 << (2 * (S + 1));
+  stage_butterflies<Q, LOGL, S, INV, TWMOD0>(x, j, tws);
   cpx w1{}, w2{}, w3{};
   if (StageKind<S + 1, M>::value != 2) {
     const int ic = j * MOD_S1;
@@ -557,14 +577,16 @@ __device__ __forceinline__ void pair_butterflies(typename Q::cpx *x, int j, TWS 
   for (int a = 0; a < 4; a++) bfly<Q, StageKind<S + 1, M>::value, INV>(&x[4 * a], w1, w2, w3);
 }
 
-// middle steps S, S+1 (in place in LDS) up to, not including, the last pair
+// middle steps (in place in LDS) from stage S up to, not including, the last pair: one single-stage step first when
+// their number is odd, then pairs.  Blocks are counted over the whole N-point image (both halves of a 2 * 4^k transform).
 template <class Q, int LOGN, int S, bool INV>
 __device__ __forceinline__ void direct_middle(typename Q::word *lds, const typename Q::tword *tl, int tid)
 {
   using PL = DirectPlan<LOGN>;
   using cpx = typename Q::cpx;
   if constexpr (S < PL::M - 2) {
-    constexpr int LOGN1 = LOGN - 2 * S, LOGQ = LOGN1 - 4;
+    constexpr bool PAIR = ((PL::M - 2 - S) % 2) == 0;
+    constexpr int LOGN1 = PL::LOGL - 2 * S, LOGQ = LOGN1 - 4;
     int blk, j;
     dlane_map<LOGN, LOGN1>(tid, blk, j);
     const int e0 = (blk << LOGN1) + j;
@@ -573,11 +595,12 @@ __device__ __forceinline__ void direct_middle(typename Q::word *lds, const typen
 #pragma unroll
     for (int c = 0; c < 16; c++) x[c] = Q::unpack(base[PL::doff(c, LOGQ)]);
     auto t4 = [&](int ic) { return tl[ic >> 2]; };
-    pair_butterflies<Q, LOGN, S, INV>(x, j, t4, t4);
+    if constexpr (PAIR) pair_butterflies<Q, PL::LOGL, S, INV, PL::TWMOD0>(x, j, t4, t4);
+    else stage_butterflies<Q, PL::LOGL, S, INV, PL::TWMOD0>(x, j, t4);
 #pragma unroll
     for (int c = 0; c < 16; c++) base[PL::doff(c, LOGQ)] = Q::pack(x[c]);
     __syncthreads();
-    direct_middle<Q, LOGN, S + 2, INV>(lds, tl, tid);
+    direct_middle<Q, LOGN, S + (PAIR ? 2 : 1), INV>(lds, tl, tid);
   }
 }
 
@@ -626,9 +649,24 @@ __global__ __launch_bounds__(DirectPlan<LOGN>::T) void cfft_fixed_direct_kernel(
   // every fourth table entry to LDS for the later stages (twidCoefModifier 4^S, S >= 1)
   for (int i = tid; i < 3 * PL::N / 16; i += T) tl[i] = tw[4 * i];
   auto tg = [&](int ic) { return tw[ic]; };
-  constexpr int S1 = (M & 1) ? 1 : 2;  // first stage of the middle steps
-  if constexpr ((M & 1) == 0) {
-    pair_butterflies<Q, LOGN, 0, INV>(x, tid, tg, tg);
+  constexpr int S1 = (PL::BY2 || (M & 1)) ? 1 : 2;  // first stage of the middle steps
+  if constexpr (PL::BY2) {
+    // radix-2 pre-stage on (point i, point i + N/2), i = tid + c*T, then stage 0 of both halves: butterfly k of half h
+    // over x[8h + k], x[8h + k + 2], x[8h + k + 4], x[8h + k + 6] (points N/8 apart), twiddle index 2 (tid + k*T)
+#pragma unroll
+    for (int c = 0; c < 8; c++) by2<Q, INV>(x[c], x[c + 8], Q::unpack(tw[tid + c * T]));
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        cpx y[4] = {x[8 * h + k], x[8 * h + k + 2], x[8 * h + k + 4], x[8 * h + k + 6]};
+        const int ic = 2 * (tid + k * T);
+        bfly<Q, 0, INV>(y, Q::unpack(tw[ic]), Q::unpack(tw[2 * ic]), Q::unpack(tw[3 * ic]));
+        x[8 * h + k] = y[0]; x[8 * h + k + 2] = y[1]; x[8 * h + k + 4] = y[2]; x[8 * h + k + 6] = y[3];
+      }
+    }
+  } else if constexpr ((M & 1) == 0) {
+    pair_butterflies<Q, LOGN, 0, INV, 1>(x, tid, tg, tg);
   } else {
     // single stage 0: butterfly k over points u + a*N/4, u = tid + k*T (x[k + 4a])
 #pragma unroll
@@ -655,12 +693,13 @@ __global__ __launch_bounds__(DirectPlan<LOGN>::T) void cfft_fixed_direct_kernel(
     const word *base = lds + PL::pad(blk << 4);
 #pragma unroll
     for (int c = 0; c < 16; c++) x[c] = Q::unpack(base[c]);
-    // stage M-2 of the pair has the uniform twiddles b * 4^(M-2) (j = 0): scalar loads from the global table
-    pair_butterflies<Q, LOGN, M - 2, INV>(x, 0, tg, tg);
+    // stage M-2 of the pair has the uniform twiddles b * TWMOD0 * 4^(M-2) (j = 0): scalar loads from the global table
+    pair_butterflies<Q, PL::LOGL, M - 2, INV, PL::TWMOD0>(x, 0, tg, tg);
 #pragma unroll
     for (int c = 0; c < 16; c++) {
       const int rc = ((c & 1) << 3) | ((c & 2) << 1) | ((c & 4) >> 1) | ((c & 8) >> 3);
-      DirectIo<Q>::store(Q::pack(x[c]), rs, tid * W, rc * T * W);
+      // (final << 1 of radix4by2: arm_cfft_q15.c:814-831, arm_cfft_q31.c:807-824)
+      DirectIo<Q>::store(Q::pack(PL::BY2 ? shl1<Q>(x[c]) : x[c]), rs, tid * W, rc * T * W);
     }
   }
 }
@@ -752,7 +791,7 @@ static hipError_t launch_fixed(int logn, typename Q::word *data, const typename 
     switch (logn) {
 #define D(L) \
   case L: return inverse ? launch_fixed_direct<Q, L, true>(data, tw, batch, stream) : launch_fixed_direct<Q, L, false>(data, tw, batch, stream);
-      D(10) D(12) D(14)
+      D(10) D(11) D(12) D(13) D(14)
 #undef D
     }
   }
