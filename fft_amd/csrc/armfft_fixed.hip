@@ -625,27 +625,17 @@ template <> struct DirectIo<Q31> {
   }
 };
 
+// The transform itself.  On entry x[c] = point tid + c*T; on return x[c] = the result whose index in bit-reversed
+// (= natural) output order is brev4(c)*T + tid, before the final << 1 of the 2 * 4^k sizes (direct_out).  `lds` = the
+// image (PL::LDS_WORDS words), `tl` = room for 3N/16 table words behind it.  Ends without a barrier: the last step only reads.
 template <class Q, int LOGN, bool INV>
-__global__ __launch_bounds__(DirectPlan<LOGN>::T) void cfft_fixed_direct_kernel(typename Q::word *__restrict__ data,
-                                                                               const typename Q::tword *__restrict__ tw, uint32_t batch)
+__device__ __forceinline__ void direct_transform(typename Q::cpx *x, typename Q::word *lds, typename Q::tword *tl,
+                                                 const typename Q::tword *__restrict__ tw, int tid)
 {
   using PL = DirectPlan<LOGN>;
   using word = typename Q::word;
-  using tword = typename Q::tword;
   using cpx = typename Q::cpx;
-  constexpr int W = sizeof(word), T = PL::T, M = PL::M;
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  word *lds = reinterpret_cast<word *>(lds_raw);
-  tword *tl = reinterpret_cast<tword *>(lds + PL::LDS_WORDS);
-  const uint32_t g = blockIdx.x + blockIdx.y * gridDim.x;
-  if (g >= batch) return;
-  const int tid = threadIdx.x;
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(data + (size_t)g * PL::N, 0, PL::N * W, 0x00020000);
-
-  // ---- first step: points tid + c*T from global memory ----
-  cpx x[16];
-#pragma unroll
-  for (int c = 0; c < 16; c++) x[c] = Q::unpack(DirectIo<Q>::load(rs, tid * W, c * T * W));
+  constexpr int T = PL::T, M = PL::M;
   // every fourth table entry to LDS for the later stages (twidCoefModifier 4^S, S >= 1)
   for (int i = tid; i < 3 * PL::N / 16; i += T) tl[i] = tw[4 * i];
   auto tg = [&](int ic) { return tw[ic]; };
@@ -687,21 +677,46 @@ __global__ __launch_bounds__(DirectPlan<LOGN>::T) void cfft_fixed_direct_kernel(
   // ---- middle steps, in place in LDS ----
   direct_middle<Q, LOGN, S1, INV>(lds, tl, tid);
 
-  // ---- last step: block brev(tid), results straight to global memory ----
-  {
-    const int blk = (int)(__brev((unsigned)tid) >> (32 - PL::LOGT));
-    const word *base = lds + PL::pad(blk << 4);
+  // ---- last step: block brev(tid) ----
+  const int blk = (int)(__brev((unsigned)tid) >> (32 - PL::LOGT));
+  const word *base = lds + PL::pad(blk << 4);
 #pragma unroll
-    for (int c = 0; c < 16; c++) x[c] = Q::unpack(base[c]);
-    // stage M-2 of the pair has the uniform twiddles b * TWMOD0 * 4^(M-2) (j = 0): scalar loads from the global table
-    pair_butterflies<Q, PL::LOGL, M - 2, INV, PL::TWMOD0>(x, 0, tg, tg);
+  for (int c = 0; c < 16; c++) x[c] = Q::unpack(base[c]);
+  // stage M-2 of the pair has the uniform twiddles b * TWMOD0 * 4^(M-2) (j = 0): scalar loads from the global table
+  pair_butterflies<Q, PL::LOGL, M - 2, INV, PL::TWMOD0>(x, 0, tg, tg);
+}
+// output index of result c of thread tid, in units of T
+__device__ __forceinline__ constexpr int direct_rc(int c) { return ((c & 1) << 3) | ((c & 2) << 1) | ((c & 4) >> 1) | ((c & 8) >> 3); }
+// result as arm_cfft_* leaves it: final << 1 of radix4by2 (arm_cfft_q15.c:814-831, arm_cfft_q31.c:807-824)
+template <class Q, int LOGN>
+__device__ __forceinline__ typename Q::cpx direct_out(typename Q::cpx v)
+{
+  return DirectPlan<LOGN>::BY2 ? shl1<Q>(v) : v;
+}
+
+template <class Q, int LOGN, bool INV>
+__global__ __launch_bounds__(DirectPlan<LOGN>::T) void cfft_fixed_direct_kernel(typename Q::word *__restrict__ data,
+                                                                               const typename Q::tword *__restrict__ tw, uint32_t batch)
+{
+  using PL = DirectPlan<LOGN>;
+  using word = typename Q::word;
+  using tword = typename Q::tword;
+  using cpx = typename Q::cpx;
+  constexpr int W = sizeof(word), T = PL::T;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  word *lds = reinterpret_cast<word *>(lds_raw);
+  tword *tl = reinterpret_cast<tword *>(lds + PL::LDS_WORDS);
+  const uint32_t g = blockIdx.x + blockIdx.y * gridDim.x;
+  if (g >= batch) return;
+  const int tid = threadIdx.x;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(data + (size_t)g * PL::N, 0, PL::N * W, 0x00020000);
+  // first step: points tid + c*T from global memory; last step: results straight back to it
+  cpx x[16];
 #pragma unroll
-    for (int c = 0; c < 16; c++) {
-      const int rc = ((c & 1) << 3) | ((c & 2) << 1) | ((c & 4) >> 1) | ((c & 8) >> 3);
-      // (final << 1 of radix4by2: arm_cfft_q15.c:814-831, arm_cfft_q31.c:807-824)
-      DirectIo<Q>::store(Q::pack(PL::BY2 ? shl1<Q>(x[c]) : x[c]), rs, tid * W, rc * T * W);
-    }
-  }
+  for (int c = 0; c < 16; c++) x[c] = Q::unpack(DirectIo<Q>::load(rs, tid * W, c * T * W));
+  direct_transform<Q, LOGN, INV>(x, lds, tl, tw, tid);
+#pragma unroll
+  for (int c = 0; c < 16; c++) DirectIo<Q>::store(Q::pack(direct_out<Q, LOGN>(x[c])), rs, tid * W, direct_rc(c) * T * W);
 }
 
 template <class Q, int LOGN, bool INV>
@@ -1032,6 +1047,91 @@ __global__ __launch_bounds__(FixedPlan<LOGN>::T, 4) void rfft_fixed_kernel(const
   }
 }
 
+// Direct form of the fixed-point real FFT (L = 1024 / 2048 / 4096 complex points, bit-reversed cfft order = the
+// reference's configuration): the complex transform is direct_transform of the complex kernel.
+//   forward: L input words straight into the first step; the results go back into the LDS image in natural order (one
+//            contiguous run per result index c across the lanes), and bin i = tid + c*T is split from X[i] and X[L-i]
+//            -- contiguous and reverse-contiguous LDS reads -- and written twice (position i and, conjugated, 2L-i);
+//   inverse: split_rifft of points i and L-i while loading (the mirrored one a descending contiguous run), transform,
+//            saturating << 1 on the direct stores.
+template <class Q, int LOGN, bool INV>
+__global__ __launch_bounds__(DirectPlan<LOGN>::T) void rfft_fixed_direct_kernel(const typename Q::word *__restrict__ in,
+                                                                               typename Q::word *__restrict__ out,
+                                                                               const typename Q::tword *__restrict__ tw,
+                                                                               const typename Q::tword *__restrict__ coefA,
+                                                                               const typename Q::tword *__restrict__ coefB, int mod,
+                                                                               uint32_t batch)
+{
+  using PL = DirectPlan<LOGN>;
+  using word = typename Q::word;
+  using tword = typename Q::tword;
+  using cpx = typename Q::cpx;
+  constexpr int W = sizeof(word), T = PL::T, L = PL::N;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  word *lds = reinterpret_cast<word *>(lds_raw);
+  tword *tl = reinterpret_cast<tword *>(lds + PL::LDS_WORDS);
+  const uint32_t g = blockIdx.x + blockIdx.y * gridDim.x;
+  if (g >= batch) return;
+  const int tid = threadIdx.x;
+  cpx x[16];
+  if (!INV) {
+    const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc(const_cast<word *>(in) + (size_t)g * L, 0, L * W, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)g * (2 * L), 0, 2 * L * W, 0x00020000);
+#pragma unroll
+    for (int c = 0; c < 16; c++) x[c] = Q::unpack(DirectIo<Q>::load(ri, tid * W, c * T * W));
+    direct_transform<Q, LOGN, false>(x, lds, tl, tw, tid);
+    __syncthreads();  // every thread has read its last-step block: the image may be overwritten
+#pragma unroll
+    for (int c = 0; c < 16; c++) lds[direct_rc(c) * T + tid] = Q::pack(direct_out<Q, LOGN>(x[c]));
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 16; c++) {
+      const int i = tid + c * T;
+      if (i == 0) {
+        const cpx x0 = Q::unpack(lds[0]);
+        DirectIo<Q>::store(Q::pack(dc_word(x0, false)), ro, 0, 0);
+        DirectIo<Q>::store(Q::pack(dc_word(x0, true)), ro, 0, L * W);
+      } else {
+        const cpx o = split_fwd(Q::unpack(lds[i]), Q::unpack(lds[L - i]), Q::unpack(coefA[i * mod]), Q::unpack(coefB[i * mod]));
+        DirectIo<Q>::store(Q::pack(o), ro, tid * W, c * T * W);
+        DirectIo<Q>::store(Q::pack(mirror(o)), ro, (2 * L - i) * W, 0);
+      }
+    }
+  } else {
+    const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc(const_cast<word *>(in) + (size_t)g * (L + 1), 0, (L + 1) * W, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)g * L, 0, L * W, 0x00020000);
+#pragma unroll
+    for (int c = 0; c < 16; c++) {
+      const int i = tid + c * T;
+      const cpx s1 = Q::unpack(DirectIo<Q>::load(ri, tid * W, c * T * W)), s2 = Q::unpack(DirectIo<Q>::load(ri, (L - i) * W, 0));
+      x[c] = split_inv(s1, s2, Q::unpack(coefA[i * mod]), Q::unpack(coefB[i * mod]));
+    }
+    direct_transform<Q, LOGN, true>(x, lds, tl, tw, tid);
+#pragma unroll
+    for (int c = 0; c < 16; c++) DirectIo<Q>::store(Q::pack(sat_shl1(direct_out<Q, LOGN>(x[c]))), ro, tid * W, direct_rc(c) * T * W);
+  }
+}
+
+template <class Q, int LOGN, bool INV>
+static hipError_t launch_rfft_fixed_direct(const typename Q::word *in, typename Q::word *out, const typename Q::tword *tw,
+                                           const typename Q::tword *A, const typename Q::tword *B, int mod, uint32_t batch, hipStream_t stream)
+{
+  using PL = DirectPlan<LOGN>;
+  constexpr size_t lds_bytes = (size_t)PL::LDS_WORDS * sizeof(typename Q::word) + (size_t)(3 * PL::N / 16) * sizeof(typename Q::tword);
+  static std::atomic<bool> attr_done[16];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  auto kern = rfft_fixed_direct_kernel<Q, LOGN, INV>;
+  if (lds_bytes > 48 * 1024 && (dev >= 16 || !attr_done[dev])) {
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+    if (dev < 16) attr_done[dev] = true;
+  }
+  const uint32_t gx = batch < 65536u ? batch : 65536u, gy = (batch + gx - 1) / gx;
+  kern<<<dim3(gx, gy, 1), PL::T, lds_bytes, stream>>>(in, out, tw, A, B, mod, batch);
+  return hipGetLastError();
+}
+
 template <class Q, int LOGN, bool INV>
 static hipError_t launch_rfft_fixed_one(const typename Q::word *in, typename Q::word *out, const typename Q::tword *tw,
                                         const typename Q::tword *A, const typename Q::tword *B, int mod, uint32_t batch, bool bitrev,
@@ -1061,6 +1161,16 @@ static hipError_t launch_rfft_fixed(int logl, const typename Q::word *in, typena
                                     bool bitrev, hipStream_t stream)
 {
   if (batch == 0) return hipSuccess;
+  if (bitrev) {
+    switch (logl) {
+#define D(L) \
+  case L:    \
+    return inverse ? launch_rfft_fixed_direct<Q, L, true>(in, out, tw, A, B, mod, batch, stream) \
+                   : launch_rfft_fixed_direct<Q, L, false>(in, out, tw, A, B, mod, batch, stream);
+      D(10) D(11) D(12)
+#undef D
+    }
+  }
   switch (logl) {
 #define C(L) \
   case L:    \
