@@ -515,9 +515,11 @@ static int rfft_fixed_log(uint32_t n_real)
   return (l >= 5 && l <= 13) ? l : -1;
 }
 
-// staging for host-pointer calls; serialised per device by g_stage_mu (these entry points are the
-// compatibility path, not the fast path)
-static std::mutex g_stage_mu;
+// staging for host-pointer calls: one pair of device buffers per GPU, so the calls of one GPU are serialised by that GPU's
+// mutex; threads driving different GPUs do not wait for each other (these entry points are the compatibility path, not
+// the fast path: pageable copies, synchronous)
+static std::mutex g_stage_mu_dev[kMaxDev];
+static std::mutex &stage_mu(int dev) { return g_stage_mu_dev[dev >= 0 && dev < kMaxDev ? dev : 0]; }
 static void *stage_buffer(int dev, size_t bytes, int which)
 {
   void *&p = which ? g_dev[dev].stage2 : g_dev[dev].stage;
@@ -554,7 +556,7 @@ static arm_status host_batch(const S *inst, T *p, uint32_t batch, size_t elems_p
   if (batch == 0) return ARM_MATH_SUCCESS;
   int dev;
   if (!current_device(&dev)) return ARM_MATH_ARGUMENT_ERROR;
-  std::lock_guard<std::mutex> lk(g_stage_mu);
+  std::lock_guard<std::mutex> lk(stage_mu(dev));
   size_t bytes = elems_per_xform * batch * sizeof(T);
   T *d = (T *)stage_buffer(dev, bytes, 0);
   if (!d) return ARM_MATH_ARGUMENT_ERROR;
@@ -797,7 +799,7 @@ static arm_status rfft_fixed_host(const S *inst, const T *src, T *dst, uint32_t 
   if (!current_device(&dev)) return ARM_MATH_ARGUMENT_ERROR;
   const size_t n = inst->fftLenReal;
   const size_t in_elems = (inst->ifftFlagR ? n + 2 : n) * batch, out_elems = (inst->ifftFlagR ? n : 2 * n) * batch;
-  std::lock_guard<std::mutex> lk(g_stage_mu);
+  std::lock_guard<std::mutex> lk(stage_mu(dev));
   T *di = (T *)stage_buffer(dev, in_elems * sizeof(T), 0), *dout = (T *)stage_buffer(dev, out_elems * sizeof(T), 1);
   if (!di || !dout) return ARM_MATH_ARGUMENT_ERROR;
   if (!hip_ok(hipMemcpy(di, src, in_elems * sizeof(T), hipMemcpyHostToDevice), "hipMemcpy(H2D)")) return ARM_MATH_ARGUMENT_ERROR;
@@ -878,7 +880,7 @@ arm_status arm_cfft_u32_batch_f32(const arm_cfft_instance_u32_f32 *S, float32_t 
   if (batch == 0) return ARM_MATH_SUCCESS;
   int dev;
   if (!current_device(&dev)) return ARM_MATH_ARGUMENT_ERROR;
-  std::lock_guard<std::mutex> lk(g_stage_mu);
+  std::lock_guard<std::mutex> lk(stage_mu(dev));
   size_t bytes = (size_t)S->fftLen * 2 * sizeof(float) * batch;
   float *d = (float *)stage_buffer(dev, bytes, 0), *w = (float *)stage_buffer(dev, bytes, 1);
   if (!d || !w) return ARM_MATH_ARGUMENT_ERROR;
@@ -1018,7 +1020,7 @@ arm_status arm_rfft_fast_batch_f32(const arm_rfft_fast_instance_f32 *S, float32_
   if (batch == 0) return ARM_MATH_SUCCESS;
   int dev;
   if (!current_device(&dev)) return ARM_MATH_ARGUMENT_ERROR;
-  std::lock_guard<std::mutex> lk(g_stage_mu);
+  std::lock_guard<std::mutex> lk(stage_mu(dev));
   size_t bytes = (size_t)S->fftLenRFFT * batch * sizeof(float);
   float *din = (float *)stage_buffer(dev, bytes, 0), *dout = (float *)stage_buffer(dev, bytes, 1);
   if (!din || !dout) return ARM_MATH_ARGUMENT_ERROR;
