@@ -71,6 +71,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the other configs' measurements (headline workload, N = 1)")
     ap.add_argument("--extra-steps", type=int, default=5)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the RCCL process group even with one rank (run under torch.distributed.run): exercises the "
+                         "barrier, the max-over-ranks reduction and, with --gnss-shard doppler, the all-gather on a single GPU")
     ap.add_argument("--gnss-shard", choices=["scenes", "doppler"], default="scenes",
                     help="GNSS workload, N > 1: scenes per rank (no collective) or Doppler bins per rank + one all-gather per step")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -534,7 +537,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: fft_amd has no CPU path")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist   # --force-dist: the RCCL group, barrier, reductions and all-gather with ONE rank too
+    if use_dist:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert lib.arm_fft_mi355_set_device(local_rank) == 0, fft_amd.last_error()
 
@@ -562,7 +566,7 @@ def main():
         w.step = step_sharded
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -579,7 +583,7 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms = state["kernel_ms"]
 
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed, kernel_ms], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = float(t[0]), float(t[1])
@@ -593,7 +597,7 @@ def main():
         assert w.acquire(0, w.n_dop) == 0, fft_amd.last_error()
         torch.cuda.synchronize()
         merge_ok = bool(torch.equal(merged, w.best.view(batch * w.n_prn, 8)))
-        if world > 1:
+        if use_dist:
             f = torch.tensor([1.0 if merge_ok else 0.0], device="cuda")
             dist.all_reduce(f, op=dist.ReduceOp.MIN)
             merge_ok = bool(f.item() == 1.0)
@@ -656,7 +660,7 @@ def main():
             torch.cuda.empty_cache()
             line["extra"] = [measure_extra(nm, args.extra_steps, stream, traffic_table, args.preheat_ms / 2) for nm in EXTRA_WORKLOADS]
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

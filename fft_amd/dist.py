@@ -52,7 +52,7 @@ def merge_best(best, group=None):
     import torch
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return best
     world = dist.get_world_size(group)
     gathered = [torch.empty_like(best) for _ in range(world)]
