@@ -163,7 +163,39 @@ __global__ __launch_bounds__(1024, 8) void fourstep_tile_kernel(const float2 *__
     }
   }
   const __amdgpu_buffer_rsrc_t ro = xform_rsrc(out + (size_t)xf * nfull, nfull);
-  if (MODE == 1) {
+  if constexpr (MODE == 1 && LOGA <= 10) {
+    // 16 or more sequences per tile: the lanes of a wave run across the sequences, so direct stores of B[seq][k] would be
+    // 8-byte pieces 2^LOGA * 8 bytes (or one pass-2 tile row) apart.  The results go through the image once more, this time
+    // sequence-major (row stride A + PADT floats: the lanes' column walk stays conflict-free), and leave with the lanes
+    // along k: element tid + 1024 i = bin tid % A of sequence tid / A + i * 1024 / A, whole 512-byte runs per wave.
+    constexpr int PADT = C >= 32 ? 1 : 32 / C, RS = A + PADT, SEQ_STEP = 1024 >> LOGA;
+    static_assert(C * RS <= IM::ELEMS, "the transposed tile fits the image");
+    float2 o[16];
+    int n = 0;
+    auto cap = [&](int, int, float2 x) { o[n++] = x; };
+    fft_block_split_il<PL, true, true, true>(v, ldsf, twl, tid, cap);
+    const int kk = tid & (A - 1), t0 = tid >> LOGA;
+    float2 y[16];
+    __syncthreads();  // the last pass has read the image
+    for_each_last_pass_output_im<PL, IM>(tid, [&](int slot, int t, int e0, int roff) { ldsf[t * RS + e0 + roff] = o[slot].x; });
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; i++) y[i].x = ldsf[(t0 + i * SEQ_STEP) * RS + kk];
+    __syncthreads();
+    for_each_last_pass_output_im<PL, IM>(tid, [&](int slot, int t, int e0, int roff) { ldsf[t * RS + e0 + roff] = o[slot].y; });
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; i++) y[i].y = ldsf[(t0 + i * SEQ_STEP) * RS + kk];
+    // B[seq][k], row-major or blocked (RowStore's layouts), seq = c0 + t0 + i * SEQ_STEP
+    const int lc2 = 14 - log_other;
+    const uint32_t seq0 = c0 + (uint32_t)t0;
+    const uint32_t row_major = (seq0 << LOGA) + (uint32_t)kk;
+    const uint32_t blocked = (((uint32_t)kk >> lc2) << 14) + (seq0 << lc2) + ((uint32_t)kk & ((1u << lc2) - 1u));
+    const uint32_t vo = (TILED ? blocked : row_major) * 8u;
+    const uint32_t so = (TILED ? (uint32_t)SEQ_STEP << lc2 : (uint32_t)SEQ_STEP << LOGA) * 8u;
+#pragma unroll
+    for (int i = 0; i < 16; i++) buf_store(ro, vo, i * so, y[i]);
+  } else if constexpr (MODE == 1) {
     RowStore<LOGA, TILED> st{ro, c0, log_other};
     fft_block_split_il<PL, true, true, true>(v, ldsf, twl, tid, st);
   } else {

@@ -725,6 +725,21 @@ __device__ __forceinline__ void fft_block_split(float2 *v, float *ldsf, const fl
   fft_split_passes<PL, SplitImage<PL>, 0, NESTED8, NESTED16, false>(v, ldsf, tw, nullptr, tid, st);
 }
 
+// f(slot, t, e0, roff) for the 16 last-pass outputs of thread tid under image policy IM, in the order fft_split_passes hands
+// them to its store functor: output slot is bin e0 + roff of sequence t
+template <class PL, class IM, class F>
+__device__ __forceinline__ void for_each_last_pass_output_im(int tid, F f)
+{
+  constexpr int P = PL::NPASS - 1, LR = PL::lr(P), R = 1 << LR, NB = PL::E / R, LNS = PL::lns(P), NS = 1 << LNS, LNR = PL::LOGN - LR;
+#pragma unroll
+  for (int q = 0; q < NB; q++) {
+    const int t = IM::seq(tid + q * PL::T, LNR), j = IM::bfly(tid + q * PL::T, LNR);
+    const int j0 = ((j >> LNS) << (LNS + LR)) + (j & (NS - 1));
+#pragma unroll
+    for (int r = 0; r < R; r++) f(q * R + r, t, j0, r << LNS);
+  }
+}
+
 // Interleaved sequences (SplitImageIL): v[q*R + r] = point bfly + r * N/R of sequence (tid + q*T) % TPB, bfly = (tid + q*T) / TPB;
 // ldsf = SplitImageIL<PL>::ELEMS floats
 template <class PL, bool NESTED8, bool NESTED16 = false, bool LATE_TW = false, class Store>
