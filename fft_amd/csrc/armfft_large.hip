@@ -67,12 +67,13 @@ struct RowStore {
   __amdgpu_buffer_rsrc_t rs;
   uint32_t c0;
   int log_seq;   // log2 of the number of sequences (rows of B)
+  int log_blk;   // log2 of the points in one pass-2 tile (= one block)
   __device__ __forceinline__ void operator()(int t, int e0, int roff, float2 v) const
   {
     const uint32_t seq = c0 + (uint32_t)t;
-    const int lc2 = 14 - log_seq;
+    const int lc2 = log_blk - log_seq;
     const uint32_t row_major = (seq << LOGA) + (uint32_t)e0;
-    const uint32_t blocked = (((uint32_t)e0 >> lc2) << 14) + (seq << lc2) + ((uint32_t)e0 & ((1u << lc2) - 1u));
+    const uint32_t blocked = (((uint32_t)e0 >> lc2) << log_blk) + (seq << lc2) + ((uint32_t)e0 & ((1u << lc2) - 1u));
     const uint32_t voff = (TILED ? blocked : row_major) * 8u;
     const uint32_t soff = (TILED ? (uint32_t)roff << log_seq : (uint32_t)roff) * 8u;
     buf_store(rs, voff, soff, v);
@@ -102,18 +103,21 @@ struct TileStore {
   }
 };
 
-template <int LOGA, int MODE, bool INV, bool TILED>
-__global__ __launch_bounds__(1024, 8) void fourstep_tile_kernel(const float2 *__restrict__ in, float2 *__restrict__ out,
-                                                                const float2 *__restrict__ tw,      // 2^LOGA-point table
-                                                                const float2 *__restrict__ tw_big,  // three-level table of W_N
-                                                                int log_other, uint32_t tiles_per_xform, uint32_t n_items, int paired,
-                                                                float scale)
+// E = points per thread: 16 (tile = 16384 points, two workgroups per CU) or 32 (tile = 32768 points, one workgroup per CU;
+// used for 2048-point sub-transforms, where it doubles the strided side's runs from 64 to 128 bytes -- whole lines).
+template <int LOGA, int MODE, bool INV, bool TILED, int E>
+__global__ __launch_bounds__(1024, E == 16 ? 8 : 4) void fourstep_tile_kernel(const float2 *__restrict__ in, float2 *__restrict__ out,
+                                                                            const float2 *__restrict__ tw,      // 2^LOGA-point table
+                                                                            const float2 *__restrict__ tw_big,  // three-level table of W_N
+                                                                            int log_other, uint32_t tiles_per_xform, uint32_t n_items, int paired,
+                                                                            int log_blk,   // MODE 1, blocked B: log2 of pass 2's tile
+                                                                            float scale)
 {
-  using PL = Plan<LOGA, 1024>;
+  using PL = Plan<LOGA, 1024, false, true, E>;
   using IM = SplitImageIL<PL>;
-  constexpr int A = PL::N, C = PL::TPB, LOGC = IM::LOGC;
-  static_assert(A * C == 16 * 1024, "16 points per thread");
-  constexpr int R0 = 1 << PL::lr(0), NB0 = 16 / R0;
+  constexpr int A = PL::N, C = PL::TPB, LOGC = IM::LOGC, LOGTILE = E == 16 ? 14 : 15;
+  static_assert(A * C == E * 1024, "E points per thread");
+  constexpr int R0 = 1 << PL::lr(0), NB0 = E / R0;
   extern __shared__ __attribute__((aligned(16))) float ldsf[];
   const uint32_t other = 1u << log_other;
   const size_t nfull = (size_t)A << log_other;
@@ -128,13 +132,13 @@ __global__ __launch_bounds__(1024, 8) void fourstep_tile_kernel(const float2 *__
   const uint32_t c0 = tile * C;
   // leg i of thread t: row t / C + i * 1024 / C, column c0 + t % C (or, from a blocked intermediate, element t + 1024 i of
   // the tile's contiguous block: the same element); butterfly q, leg r of the first pass is leg i = q + r * NB0
-  float2 v[16];
+  float2 v[E];
   const __amdgpu_buffer_rsrc_t rs = xform_rsrc(in + (size_t)xf * nfull, nfull);
   constexpr bool linear_in = (MODE == 2) && TILED;
-  const uint32_t voff = (linear_in ? (tile << 14) + (uint32_t)tid : ((uint32_t)tid >> LOGC) * other + c0 + ((uint32_t)tid & (C - 1))) * 8u;
+  const uint32_t voff = (linear_in ? (tile << LOGTILE) + (uint32_t)tid : ((uint32_t)tid >> LOGC) * other + c0 + ((uint32_t)tid & (C - 1))) * 8u;
   const uint32_t step = linear_in ? 1024u * 8u : (1024u >> LOGC) * other * 8u;
 #pragma unroll
-  for (int i = 0; i < 16; i++) v[(i % NB0) * R0 + i / NB0] = buf_load(rs, voff, i * step);
+  for (int i = 0; i < E; i++) v[(i % NB0) * R0 + i / NB0] = buf_load(rs, voff, i * step);
   // The passes' twiddle bases are entries below A/2 of the A-point table: an LDS copy, so that no pass waits for a
   // global load queued behind the other resident workgroup's tile traffic (first read after the first exchange's barriers)
   float2 *big = reinterpret_cast<float2 *>(ldsf + IM::ELEMS);
@@ -144,7 +148,7 @@ __global__ __launch_bounds__(1024, 8) void fourstep_tile_kernel(const float2 *__
   if (MODE == 1) {
     if (INV) {
 #pragma unroll
-      for (int i = 0; i < 16; i++) v[i].y = -v[i].y;  // inverse = conj(FFT(conj x)) / N
+      for (int i = 0; i < E; i++) v[i].y = -v[i].y;  // inverse = conj(FFT(conj x)) / N
     }
   } else {
     // B[row][col] *= W_N^(row * col): row = t / C + i * 1024 / C, col = c0 + t % C; the exponent advances by a constant
@@ -155,7 +159,7 @@ __global__ __launch_bounds__(1024, 8) void fourstep_tile_kernel(const float2 *__
     uint32_t m = ((uint32_t)tid >> LOGC) * col;
     const uint32_t dm = (1024u >> LOGC) * col;
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
+    for (int i = 0; i < E; i++) {
       const float2 w = cmul(cmul(big[kBigA + (m & 127u)], big[kBigB + ((m >> 7) & 127u)]), big[kBigC + (m >> 14)]);
       float2 &x = v[(i % NB0) * R0 + i / NB0];
       x = cmul(x, w);
@@ -163,57 +167,56 @@ __global__ __launch_bounds__(1024, 8) void fourstep_tile_kernel(const float2 *__
     }
   }
   const __amdgpu_buffer_rsrc_t ro = xform_rsrc(out + (size_t)xf * nfull, nfull);
-  if constexpr (MODE == 1 && LOGA <= 10) {
+  if constexpr (MODE == 1 && C >= 16) {
     // 16 or more sequences per tile: the lanes of a wave run across the sequences, so direct stores of B[seq][k] would be
     // 8-byte pieces 2^LOGA * 8 bytes (or one pass-2 tile row) apart.  The results go through the image once more, this time
     // sequence-major (row stride A + PADT floats: the lanes' column walk stays conflict-free), and leave with the lanes
-    // along k: element tid + 1024 i = bin tid % A of sequence tid / A + i * 1024 / A, whole 512-byte runs per wave.
-    constexpr int PADT = C >= 32 ? 1 : 32 / C, RS = A + PADT, SEQ_STEP = 1024 >> LOGA;
+    // along k: element m = tid + 1024 i = bin m % A of sequence m / A, whole 512-byte runs per wave.
+    constexpr int PADT = C >= 32 ? 1 : 32 / C, RS = A + PADT;
     static_assert(C * RS <= IM::ELEMS, "the transposed tile fits the image");
-    float2 o[16];
+    float2 o[E];
     int n = 0;
     auto cap = [&](int, int, float2 x) { o[n++] = x; };
-    fft_block_split_il<PL, true, true, true>(v, ldsf, twl, tid, cap);
-    const int kk = tid & (A - 1), t0 = tid >> LOGA;
-    float2 y[16];
+    fft_block_split_il<PL, E == 16, E == 16, true>(v, ldsf, twl, tid, cap);
+    float2 y[E];
     __syncthreads();  // the last pass has read the image
     for_each_last_pass_output_im<PL, IM>(tid, [&](int slot, int t, int e0, int roff) { ldsf[t * RS + e0 + roff] = o[slot].x; });
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 16; i++) y[i].x = ldsf[(t0 + i * SEQ_STEP) * RS + kk];
+    for (int i = 0; i < E; i++) y[i].x = ldsf[((tid + i * 1024) >> LOGA) * RS + ((tid + i * 1024) & (A - 1))];
     __syncthreads();
     for_each_last_pass_output_im<PL, IM>(tid, [&](int slot, int t, int e0, int roff) { ldsf[t * RS + e0 + roff] = o[slot].y; });
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 16; i++) y[i].y = ldsf[(t0 + i * SEQ_STEP) * RS + kk];
-    // B[seq][k], row-major or blocked (RowStore's layouts), seq = c0 + t0 + i * SEQ_STEP
-    const int lc2 = 14 - log_other;
-    const uint32_t seq0 = c0 + (uint32_t)t0;
-    const uint32_t row_major = (seq0 << LOGA) + (uint32_t)kk;
-    const uint32_t blocked = (((uint32_t)kk >> lc2) << 14) + (seq0 << lc2) + ((uint32_t)kk & ((1u << lc2) - 1u));
-    const uint32_t vo = (TILED ? blocked : row_major) * 8u;
-    const uint32_t so = (TILED ? (uint32_t)SEQ_STEP << lc2 : (uint32_t)SEQ_STEP << LOGA) * 8u;
+    for (int i = 0; i < E; i++) y[i].y = ldsf[((tid + i * 1024) >> LOGA) * RS + ((tid + i * 1024) & (A - 1))];
+    // B[seq][k], row-major or blocked (RowStore's layouts)
+    const int lc2 = log_blk - log_other;
 #pragma unroll
-    for (int i = 0; i < 16; i++) buf_store(ro, vo, i * so, y[i]);
+    for (int i = 0; i < E; i++) {
+      const uint32_t seq = c0 + (uint32_t)((tid + i * 1024) >> LOGA), kk = (uint32_t)((tid + i * 1024) & (A - 1));
+      const uint32_t row_major = (seq << LOGA) + kk;
+      const uint32_t blocked = ((kk >> lc2) << log_blk) + (seq << lc2) + (kk & ((1u << lc2) - 1u));
+      buf_store(ro, (TILED ? blocked : row_major) * 8u, 0, y[i]);
+    }
   } else if constexpr (MODE == 1) {
-    RowStore<LOGA, TILED> st{ro, c0, log_other};
-    fft_block_split_il<PL, true, true, true>(v, ldsf, twl, tid, st);
+    RowStore<LOGA, TILED> st{ro, c0, log_other, log_blk};
+    fft_block_split_il<PL, E == 16, E == 16, true>(v, ldsf, twl, tid, st);
   } else {
     TileStore<INV> st{ro, other, c0, scale};
-    fft_block_split_il<PL, true, true, true>(v, ldsf, twl, tid, st);
+    fft_block_split_il<PL, E == 16, E == 16, true>(v, ldsf, twl, tid, st);
   }
 }
 
-template <int LOGA, int MODE, bool INV, bool TILED>
+template <int LOGA, int MODE, bool INV, bool TILED, int E>
 static hipError_t launch_pass(const float2 *in, float2 *out, const float2 *tw, const float2 *tw_big, int log_other, uint32_t batch,
-                              float scale, hipStream_t stream)
+                              int log_blk, float scale, hipStream_t stream)
 {
-  using PL = Plan<LOGA, 1024>;
+  using PL = Plan<LOGA, 1024, false, true, E>;
   const size_t lds_bytes = SplitImageIL<PL>::LDS_BYTES + sizeof(float2) * ((MODE == 2 ? kBigEntries : 0) + PL::N / 2);
   static std::atomic<bool> attr_done[16];  // zero-initialised; a racing second hipFuncSetAttribute is harmless
   int dev = 0;
   (void)hipGetDevice(&dev);
-  auto kern = fourstep_tile_kernel<LOGA, MODE, INV, TILED>;
+  auto kern = fourstep_tile_kernel<LOGA, MODE, INV, TILED, E>;
   if (dev >= 16 || !attr_done[dev]) {
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
@@ -222,9 +225,9 @@ static hipError_t launch_pass(const float2 *in, float2 *out, const float2 *tw, c
   const uint32_t tiles = (1u << log_other) / PL::TPB;
   const uint64_t n_items = (uint64_t)tiles * batch;
   if (n_items > 0x7fffffffull) return hipErrorInvalidValue;
-  // pair mapping: whole pairs, and a grid that is a multiple of 16 (two slots on each of the 8 XCDs)
-  const int paired = (MODE == 1 && tiles % 2 == 0 && n_items % 16 == 0) ? 1 : 0;
-  kern<<<(uint32_t)n_items, 1024, lds_bytes, stream>>>(in, out, tw, tw_big, log_other, tiles, (uint32_t)n_items, paired, scale);
+  // pair mapping (64-byte runs only): whole pairs, and a grid that is a multiple of 16 (two slots on each of the 8 XCDs)
+  const int paired = (MODE == 1 && PL::TPB == 8 && tiles % 2 == 0 && n_items % 16 == 0) ? 1 : 0;
+  kern<<<(uint32_t)n_items, 1024, lds_bytes, stream>>>(in, out, tw, tw_big, log_other, tiles, (uint32_t)n_items, paired, log_blk, scale);
   return hipGetLastError();
 }
 
@@ -253,17 +256,20 @@ hipError_t launch_gen_twiddle_lo(float2 *tw, int logn, hipStream_t stream)
 // multiple of pass 2's tile width C2 = 16384 / N2, which holds for N1 >= 512, i.e. N >= 2^17:
 // pass 1 (LOGA = log2 N1) is blocked from LOGA = 9, pass 2 (LOGA = log2 N2) from LOGA = 9 and,
 // for N = 2^17 only, at LOGA = 8.
+// points per thread of the kernel that runs 2^loga-point sub-transforms (see fourstep_tile_kernel)
+static int tile_e(int loga) { return loga == 11 ? 32 : 16; }
+
 template <int MODE, bool INV>
 static hipError_t launch_pass_log(int loga, const float2 *in, float2 *out, const float2 *tw, const float2 *tw_big, int log_other,
-                                  uint32_t batch, float scale, bool tiled, hipStream_t stream)
+                                  uint32_t batch, int log_blk, float scale, bool tiled, hipStream_t stream)
 {
   switch (loga) {
-#define C(L, T) case L: return launch_pass<L, MODE, INV, T>(in, out, tw, tw_big, log_other, batch, scale, stream);
-    C(7, false)
+#define C(L, T, E) case L: return launch_pass<L, MODE, INV, T, E>(in, out, tw, tw_big, log_other, batch, log_blk, scale, stream);
+    C(7, false, 16)
     case 8:
-      if (MODE == 2 && tiled) return launch_pass<8, MODE, INV, (MODE == 2)>(in, out, tw, tw_big, log_other, batch, scale, stream);
-      return launch_pass<8, MODE, INV, false>(in, out, tw, tw_big, log_other, batch, scale, stream);
-    C(9, true) C(10, true) C(11, true)
+      if (MODE == 2 && tiled) return launch_pass<8, MODE, INV, (MODE == 2), 16>(in, out, tw, tw_big, log_other, batch, log_blk, scale, stream);
+      return launch_pass<8, MODE, INV, false, 16>(in, out, tw, tw_big, log_other, batch, log_blk, scale, stream);
+    C(9, true, 16) C(10, true, 16) C(11, true, 32)
 #undef C
   }
   return hipErrorInvalidValue;
@@ -277,15 +283,16 @@ hipError_t launch_cfft_large_f32(int logn, float2 *data, float2 *work, const flo
   const int log2_ = logn / 2, log1 = logn - log2_;  // N1 >= N2
   const float scale = 1.0f / (float)(1ull << logn);
   const bool tiled = logn >= 17;
+  const int log_blk = tile_e(log2_) == 32 ? 15 : 14;  // the block of the blocked intermediate = pass 2's tile
   hipError_t e;
   if (!inverse) {
-    e = launch_pass_log<1, false>(log1, data, work, tw1, tw_big, log2_, batch, 1.0f, tiled, stream);
+    e = launch_pass_log<1, false>(log1, data, work, tw1, tw_big, log2_, batch, log_blk, 1.0f, tiled, stream);
     if (e != hipSuccess) return e;
-    return launch_pass_log<2, false>(log2_, work, data, tw2, tw_big, log1, batch, 1.0f, tiled, stream);
+    return launch_pass_log<2, false>(log2_, work, data, tw2, tw_big, log1, batch, log_blk, 1.0f, tiled, stream);
   }
-  e = launch_pass_log<1, true>(log1, data, work, tw1, tw_big, log2_, batch, 1.0f, tiled, stream);
+  e = launch_pass_log<1, true>(log1, data, work, tw1, tw_big, log2_, batch, log_blk, 1.0f, tiled, stream);
   if (e != hipSuccess) return e;
-  return launch_pass_log<2, true>(log2_, work, data, tw2, tw_big, log1, batch, scale, tiled, stream);
+  return launch_pass_log<2, true>(log2_, work, data, tw2, tw_big, log1, batch, log_blk, scale, tiled, stream);
 }
 
 }  // namespace armfft

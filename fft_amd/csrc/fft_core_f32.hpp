@@ -166,15 +166,15 @@ __device__ __forceinline__ void butterfly(float2 *v)
 }
 
 // ---- compile-time plan ----
-// Plan<LOGN, TT, PP, PK>: TT threads per workgroup (0 = default: 256 below 4096 points, N/16 above).
+// Plan<LOGN, TT, PP, PK, EE>: TT threads per workgroup (0 = default: 256 below 4096 points, N/16 above).
 // PP: two LDS images used alternately (pass p writes image p & 1), which removes the barrier between
 // a middle pass's reads and its writes -- for kernels that run few workgroups per CU and have the
 // LDS to spare.
-template <int LOGN_, int TT = 0, bool PP = false, bool PK = true>
+template <int LOGN_, int TT = 0, bool PP = false, bool PK = true, int EE = 16>
 struct Plan {
   using AR = typename std::conditional<PK, ArPk, ArSc>::type;  // complex arithmetic of the passes (see ArPk / ArSc)
   static constexpr bool PINGPONG = PP;
-  static constexpr int E = 16;  // points per thread and pass
+  static constexpr int E = EE;  // points per thread and pass (16; 32 in the four-step's double tiles, split exchange only)
   static constexpr int LOGN = LOGN_;
   static constexpr int N = 1 << LOGN;
   static constexpr int NPASS = (LOGN + 3) / 4;
