@@ -381,15 +381,44 @@ __device__ __forceinline__ Top2 top2_scan(Mag mag, int n, int sep, int tid, void
   return r;
 }
 
-// compute_snr_cplx (gnss_codes.c:1110-1125) and InterpolateCodePhase (:1096-1108) on the finished row
+// A scanned row before its scalar arithmetic.  finish_row is a chain of ~160 dependent double-precision
+// instructions (two divisions, a log10) that one lane would run per row while its workgroup waits; the fused
+// kernels park the rows in LDS instead and finish up to kPendRows of them in one pass, one lane per row, so the
+// chain is issued once per kPendRows rows (measured: 8 % of the GPS L1 acquisition).
+struct RowRaw {
+  float v1, v2;
+  int i1, i2;
+  double sum;
+  float m2, m1, p1, p2;  // mag(i1 - 2), mag((i1 + n - 1) % n), mag((i1 + 1) % n), mag(i1 + 2); 0 where the index is out of range
+};
+constexpr int kPendRows = 64;  // one wave finishes them: writer (lane 0) and readers are the same wave
+constexpr size_t pend_bytes() { return kPendRows * sizeof(RowRaw); }
+
 template <class Mag>
-__device__ __forceinline__ void finish_row(const Top2 &t, Mag mag, int n, int dop_bin, int prn, gnss_acq_result *out)
+__device__ __forceinline__ RowRaw gather_row(const Top2 &t, Mag mag, int n)
 {
+  RowRaw r;
+  r.v1 = t.v1, r.v2 = t.v2, r.i1 = t.i1, r.i2 = t.i2, r.sum = t.sum;
+  r.m2 = (t.i1 - 2 >= 0 && t.i1 - 2 < n) ? mag(t.i1 - 2) : 0.f;
+  r.m1 = mag((t.i1 + n - 1) % n);
+  r.p1 = mag((t.i1 + 1) % n);
+  r.p2 = (t.i1 + 2 >= 0 && t.i1 + 2 < n) ? mag(t.i1 + 2) : 0.f;
+  return r;
+}
+
+// compute_snr_cplx (gnss_codes.c:1110-1125) and InterpolateCodePhase (:1096-1108) on the finished row
+__device__ __forceinline__ void finish_row(const RowRaw &t, int n, int dop_bin, int prn, gnss_acq_result *out)
+{
+  // the five samples around the peak leave the noise sum in index order, those outside the row are skipped;
+  // where i1 - 1 / i1 + 1 lie inside the row the wrapped neighbours m1 / p1 are those samples, and mag(i1) is v1
   double off = t.sum;
-  for (int i = t.i1 - 2; i <= t.i1 + 2; i++)
-    if (i >= 0 && i < n) off -= (double)mag(i);
+  if (t.i1 - 2 >= 0 && t.i1 - 2 < n) off -= (double)t.m2;
+  if (t.i1 - 1 >= 0 && t.i1 - 1 < n) off -= (double)t.m1;
+  if (t.i1 >= 0 && t.i1 < n) off -= (double)t.v1;
+  if (t.i1 + 1 >= 0 && t.i1 + 1 < n) off -= (double)t.p1;
+  if (t.i1 + 2 >= 0 && t.i1 + 2 < n) off -= (double)t.p2;
   const double mean = off / (double)(n - 5);
-  const double early = (double)mag((t.i1 + n - 1) % n), late = (double)mag((t.i1 + 1) % n), prompt = (double)t.v1;
+  const double early = (double)t.m1, late = (double)t.p1, prompt = (double)t.v1;
   double xi, interp;
   if (late > early) {
     xi = 0.5 * (late - early) / (prompt - early);
@@ -408,6 +437,21 @@ __device__ __forceinline__ void finish_row(const Top2 &t, Mag mag, int n, int do
   r.snr_db = (float)(10.0 * log10(prompt / mean));
   r.code_phase_interp = (float)interp;
   *out = r;
+}
+
+// Row p of a (scene, Doppler bin) is parked by lane 0 (before a barrier of the caller); rows [p - p % kPendRows, p]
+// are finished by the first lanes once the buffer is full or p is the last row.
+template <class Mag>
+__device__ __forceinline__ void park_row(RowRaw *pend, const Top2 &t, Mag mag, int n, int p, int tid)
+{
+  if (tid == 0) pend[p % kPendRows] = gather_row(t, mag, n);
+}
+__device__ __forceinline__ void flush_rows(const RowRaw *pend, int n, int p, int n_prn, int d, const int32_t *__restrict__ prns,
+                                           gnss_acq_result *__restrict__ rows_of_scene, int n_dop, int tid)
+{
+  if (p % kPendRows != kPendRows - 1 && p != n_prn - 1) return;
+  const int first = p - p % kPendRows;
+  if (tid <= p - first) finish_row(pend[tid], n, d, prns[first + tid], rows_of_scene + (size_t)(first + tid) * n_dop + d);
 }
 
 // probe: find_top2_peaks_{real,cplx} on `batch` rows of n samples in global memory
@@ -564,9 +608,10 @@ __global__ __launch_bounds__(GPlan<LOGN>::T, GPlan<LOGN>::T >= 1024 ? 4 : 3) voi
   constexpr int N = PL::N, T = PL::T;
   extern __shared__ __attribute__((aligned(16))) float2 lds[];
   // LDS map: [0, LDS_ELEMS) FFT image (the magnitude row aliases its head), then the exchange
-  // scratch of top2_scan, then the per-block phasors w[b]
+  // scratch of top2_scan, then the per-block phasors w[b], then the parked rows
   unsigned char *xch = reinterpret_cast<unsigned char *>(lds + PL::LDS_ELEMS);
   float2 *wblk = reinterpret_cast<float2 *>(xch + top2_scratch_bytes(T));
+  RowRaw *pend = reinterpret_cast<RowRaw *>(wblk + kMaxMs);
   float *magl = reinterpret_cast<float *>(lds);
   auto mag_idx = [](int m) { return m + ((m >> 4) << 2); };  // 16 floats + 4 pad: conflict-free 16-byte chunk reads
 
@@ -614,8 +659,9 @@ __global__ __launch_bounds__(GPlan<LOGN>::T, GPlan<LOGN>::T >= 1024 ? 4 : 3) voi
     __syncthreads();
     auto mag = [&](int m) -> float { return magl[mag_idx(m)]; };
     const Top2 t = top2_scan<T, 16, true>(mag, N, sep, lt, xch);
-    if (lt == 0) finish_row(t, mag, N, d, prns[p], all + ((size_t)scene * n_prn + p) * n_dop + d);
+    park_row(pend, t, mag, N, p, lt);
     __syncthreads();  // the row is dead: the next IFFT may overwrite it
+    flush_rows(pend, N, p, n_prn, d, prns, all + (size_t)scene * n_prn * n_dop, n_dop, lt);
   }
 }
 
@@ -660,6 +706,7 @@ __global__ __launch_bounds__(GPlan<LOGN>::T, GPlan<LOGN>::T >= 1024 ? 4 : 2) voi
   constexpr int N = PL::N, T = PL::T;
   extern __shared__ __attribute__((aligned(16))) float2 lds[];
   unsigned char *xch = reinterpret_cast<unsigned char *>(lds + PL::LDS_ELEMS);
+  RowRaw *pend = reinterpret_cast<RowRaw *>(xch + top2_scratch_bytes(T));
   float *magl = reinterpret_cast<float *>(lds);
   auto mag_idx = [](int m) { return m + ((m >> 4) << 2); };
   const int tid = threadIdx.x, d = dop_begin + blockIdx.x, scene = blockIdx.y;
@@ -704,8 +751,9 @@ __global__ __launch_bounds__(GPlan<LOGN>::T, GPlan<LOGN>::T >= 1024 ? 4 : 2) voi
     __syncthreads();
     auto mag = [&](int m) -> float { return magl[mag_idx(m)]; };
     const Top2 t = top2_scan<T, 16, true>(mag, N, sep, tid, xch);
-    if (tid == 0) finish_row(t, mag, N, d, prns[p], all + ((size_t)scene * n_prn + p) * n_dop + d);
+    park_row(pend, t, mag, N, p, tid);
     __syncthreads();
+    flush_rows(pend, N, p, n_prn, d, prns, all + (size_t)scene * n_prn * n_dop, n_dop, tid);
   }
 }
 
@@ -776,7 +824,7 @@ hipError_t launch_acquire(const gnss_acq_plan *pl, const void *sig, int packed, 
                           hipStream_t s)
 {
   using PL = GPlan<LOGN>;
-  const size_t lds = PL::LDS_BYTES + top2_scratch_bytes(PL::T) + kMaxMs * sizeof(float2);
+  const size_t lds = PL::LDS_BYTES + top2_scratch_bytes(PL::T) + kMaxMs * sizeof(float2) + pend_bytes();
   auto k = gnss_acquire_kernel<LOGN>;
   static std::atomic<bool> done[16];
   hipError_t e = lds_attr_once(k, lds, done, pl->device);
@@ -792,7 +840,7 @@ hipError_t launch_groups(const gnss_acq_plan *pl, const void *sig, int packed, u
 {
   using PL = GPlan<LOGN>;
   const size_t lds_a = PL::LDS_BYTES + kMaxMs * sizeof(float2);
-  const size_t lds_b = PL::LDS_BYTES + top2_scratch_bytes(PL::T);
+  const size_t lds_b = PL::LDS_BYTES + top2_scratch_bytes(PL::T) + pend_bytes();
   auto ka = gnss_group_spectra_kernel<LOGN>;
   static std::atomic<bool> done_a[16], done_b1[16], done_b2[16];
   hipError_t e = lds_attr_once(ka, lds_a, done_a, pl->device);
