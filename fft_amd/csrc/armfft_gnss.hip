@@ -549,6 +549,15 @@ __global__ void gnss_decode_ors_kernel(const uint8_t *__restrict__ data, uint32_
 // Wipe-off + coherent fold of milliseconds [ms0, ms0 + count) + forward FFT; on return (after the
 // trailing barrier) lds[PL::idx(0, k)] holds the spectrum in natural order.  The carrier phase is
 // referenced to sample 0 of the scene, so groups of milliseconds stay phase-continuous.
+// acc + a w, two packed multiply-adds: (a.x w.x, a.x w.y) + acc, then (-a.y w.y, a.y w.x) on top
+__device__ __forceinline__ float2 cmac(float2 acc, float2 a, float2 w)
+{
+  v2f r, q;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(r) : "v"(tov(a)), "v"(tov(w)), "v"(tov(acc)));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(q) : "v"(tov(a)), "v"(tov(w)), "v"(r));
+  return tof(q);
+}
+
 template <class PL>
 __device__ __forceinline__ void fold_and_fft(float2 *lds, float2 *wblk, const float2 *__restrict__ tw, const float2 *__restrict__ sig,
                                              const uint8_t *__restrict__ ors, int packed, double fd, double FS, int ms0, int count, int spm,
@@ -563,26 +572,37 @@ __device__ __forceinline__ void fold_and_fft(float2 *lds, float2 *wblk, const fl
     wblk[tid] = make_float2((float)c, (float)(-s));
   }
   __syncthreads();
+  // fold: the block phasors are the same for every point, so the blocks are the outer loop -- one phasor read, N/T
+  // independent loads in flight and two packed multiply-adds per sample, the sums held in registers
+  constexpr int PT = N / T;
+  float2 acc[PT];
+#pragma unroll
+  for (int j = 0; j < PT; j++) acc[j] = make_float2(0.f, 0.f);
+#pragma unroll 1
+  for (int b = 0; b < count; b++) {
+    const float2 w = wblk[b];
+    const int base = (ms0 + b) * spm;
+    float2 xv[PT];
+#pragma unroll
+    for (int j = 0; j < PT; j++) {
+      const int e = tid + j * T;
+      xv[j] = make_float2(0.f, 0.f);
+      if (e < spm) xv[j] = packed ? ors_sample(ors, base + e) : sig[base + e];
+    }
+#pragma unroll
+    for (int j = 0; j < PT; j++) acc[j] = cmac(acc[j], xv[j], w);
+  }
+#pragma unroll
+  for (int j = 0; j < PT; j++) lds[PL::idx(0, tid + j * T)] = acc[j];
+  // carrier wipe-off of the folded millisecond (every thread revisits its own points: no barrier)
   // one point at a time: the double-precision phase is register-hungry
 #pragma unroll 1
-  for (int e = tid; e < N; e += T) {
-    float2 acc = make_float2(0.f, 0.f);
-    if (e < spm) {
-#pragma unroll 2
-      for (int b = 0; b < count; b++) {
-        const int n = (ms0 + b) * spm + e;
-        const float2 xv = packed ? ors_sample(ors, n) : sig[n];
-        const float2 w = wblk[b];
-        acc.x += xv.x * w.x - xv.y * w.y;
-        acc.y += xv.x * w.y + xv.y * w.x;
-      }
-      double cyc = fd * (double)e / FS;
-      cyc -= floor(cyc);
-      double s, c;
-      sincospi(2.0 * cyc, &s, &c);
-      acc = cmul(acc, make_float2((float)c, (float)(-s)));
-    }
-    lds[PL::idx(0, e)] = acc;
+  for (int e = tid; e < spm; e += T) {
+    double cyc = fd * (double)e / FS;
+    cyc -= floor(cyc);
+    double s, c;
+    sincospi(2.0 * cyc, &s, &c);
+    lds[PL::idx(0, e)] = cmul(lds[PL::idx(0, e)], make_float2((float)c, (float)(-s)));
   }
   __syncthreads();
   {
