@@ -41,17 +41,24 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t xform_rsrc(const float2 *base,
   // gfx9 raw buffer: stride 0, range in bytes, 32-bit data format (<= 32 MiB per transform here)
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(base), 0, (int)(n_points * sizeof(float2)), 0x00020000);
 }
+// Cache policy of the two passes (aux of the buffer instructions, 2 = nt): the input streams in and the output streams
+// out without taking room in the 256 MiB Infinity Cache, the intermediate is written cacheable -- pass 2 finds part of it
+// there -- and read for the last time.  Same-box A/B against all-default: 2^22 x 8 0.272 -> 0.235 ms, 2^20 x 32 0.226 ->
+// 0.174, 2^16 x 1024 (512 MiB) 0.41 against 0.35 of the roofline, 2^22 x 64 (2 GiB) unchanged.
+constexpr int NT_L1 = 2, NT_S1 = 0, NT_L2 = 2, NT_S2 = 2;
+template <int AUX = 0>
 __device__ __forceinline__ float2 buf_load(const __amdgpu_buffer_rsrc_t &rs, uint32_t voff, uint32_t soff)
 {
-  const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)voff, (int)soff, 0);
+  const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)voff, (int)soff, AUX);
   return make_float2(__uint_as_float(w[0]), __uint_as_float(w[1]));
 }
+template <int AUX = 0>
 __device__ __forceinline__ void buf_store(const __amdgpu_buffer_rsrc_t &rs, uint32_t voff, uint32_t soff, float2 x)
 {
   u32x2 w;
   w[0] = __float_as_uint(x.x);
   w[1] = __float_as_uint(x.y);
-  __builtin_amdgcn_raw_buffer_store_b64(w, rs, (int)voff, (int)soff, 0);
+  __builtin_amdgcn_raw_buffer_store_b64(w, rs, (int)voff, (int)soff, AUX);
 }
 
 // MODE 1 store: output bin k = e0 + roff of sequence seq goes to the intermediate B[seq][k].  Layout of B: row-major
@@ -76,7 +83,7 @@ struct RowStore {
     const uint32_t blocked = (((uint32_t)e0 >> lc2) << log_blk) + (seq << lc2) + ((uint32_t)e0 & ((1u << lc2) - 1u));
     const uint32_t voff = (TILED ? blocked : row_major) * 8u;
     const uint32_t soff = (TILED ? (uint32_t)roff << log_seq : (uint32_t)roff) * 8u;
-    buf_store(rs, voff, soff, v);
+    buf_store<NT_S1>(rs, voff, soff, v);
   }
 };
 
@@ -99,7 +106,7 @@ struct TileStore {
   __device__ __forceinline__ void operator()(int t, int e0, int roff, float2 x) const
   {
     if (INV) x = make_float2(x.x * scale, -x.y * scale);
-    buf_store(rs, ((uint32_t)e0 * other + c0 + (uint32_t)t) * 8u, (uint32_t)roff * other * 8u, x);
+    buf_store<NT_S2>(rs, ((uint32_t)e0 * other + c0 + (uint32_t)t) * 8u, (uint32_t)roff * other * 8u, x);
   }
 };
 
@@ -138,7 +145,7 @@ __global__ __launch_bounds__(1024, E == 16 ? 8 : 4) void fourstep_tile_kernel(co
   const uint32_t voff = (linear_in ? (tile << LOGTILE) + (uint32_t)tid : ((uint32_t)tid >> LOGC) * other + c0 + ((uint32_t)tid & (C - 1))) * 8u;
   const uint32_t step = linear_in ? 1024u * 8u : (1024u >> LOGC) * other * 8u;
 #pragma unroll
-  for (int i = 0; i < E; i++) v[(i % NB0) * R0 + i / NB0] = buf_load(rs, voff, i * step);
+  for (int i = 0; i < E; i++) v[(i % NB0) * R0 + i / NB0] = buf_load<(MODE == 1 ? NT_L1 : NT_L2)>(rs, voff, i * step);
   // The passes' twiddle bases are entries below A/2 of the A-point table: an LDS copy, so that no pass waits for a
   // global load queued behind the other resident workgroup's tile traffic (first read after the first exchange's barriers)
   float2 *big = reinterpret_cast<float2 *>(ldsf + IM::ELEMS);
@@ -196,7 +203,7 @@ __global__ __launch_bounds__(1024, E == 16 ? 8 : 4) void fourstep_tile_kernel(co
       const uint32_t seq = c0 + (uint32_t)((tid + i * 1024) >> LOGA), kk = (uint32_t)((tid + i * 1024) & (A - 1));
       const uint32_t row_major = (seq << LOGA) + kk;
       const uint32_t blocked = ((kk >> lc2) << log_blk) + (seq << lc2) + (kk & ((1u << lc2) - 1u));
-      buf_store(ro, (TILED ? blocked : row_major) * 8u, 0, y[i]);
+      buf_store<NT_S1>(ro, (TILED ? blocked : row_major) * 8u, 0, y[i]);
     }
   } else if constexpr (MODE == 1) {
     RowStore<LOGA, TILED> st{ro, c0, log_other, log_blk};

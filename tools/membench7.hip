@@ -1,5 +1,6 @@
 // membench7: the four-step passes' access shapes without the arithmetic.  8 transforms of 2^22 complex f32 points as
-// 2048 x 2048 matrices; a workgroup of 1024 threads moves one tile of 2048 rows x C columns (16 x 8 bytes per lane).
+// 2048 x 2048 matrices; a workgroup of 1024 threads moves one tile of 2048 rows x C columns (E x 8 bytes per lane,
+// E = 2 C: 16 for the 2048 x 8 tiles, 32 for the 2048 x 16 tiles).
 //   mode 1: read the tile strided (runs of C*8 bytes, 16 KiB apart), write it as one contiguous block
 //   mode 2: read one contiguous block, write the tile strided
 //   mode 0: contiguous both ways (ceiling)
@@ -16,7 +17,7 @@
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
-template <int MODE, int C, int AUX, bool PAIRED>
+template <int MODE, int C, int AUX, bool PAIRED, int E = 2 * C>
 __global__ __launch_bounds__(1024) void tile_kernel(const unsigned *__restrict__ src, unsigned *__restrict__ dst, int touch)
 {
   extern __shared__ unsigned lds[];
@@ -34,22 +35,22 @@ __global__ __launch_bounds__(1024) void tile_kernel(const unsigned *__restrict__
   const unsigned t = threadIdx.x;
   const unsigned strided = ((t / C) * ROW + tile * C + t % C) * 8u, step_s = (1024u / C) * ROW * 8u;
   const unsigned linear = ((tile * (ROW * C)) + t) * 8u, step_l = 1024u * 8u;
-  u32x2 v[16];
+  u32x2 v[E];
   if (MODE == 1) {
 #pragma unroll
-    for (int i = 0; i < 16; i++) v[i] = __builtin_amdgcn_raw_buffer_load_b64(rs, strided, i * step_s, AUX);
+    for (int i = 0; i < E; i++) v[i] = __builtin_amdgcn_raw_buffer_load_b64(rs, strided, i * step_s, AUX);
 #pragma unroll
-    for (int i = 0; i < 16; i++) { v[i][0] += 1; __builtin_amdgcn_raw_buffer_store_b64(v[i], rd, linear, i * step_l, AUX); }
+    for (int i = 0; i < E; i++) { v[i][0] += 1; __builtin_amdgcn_raw_buffer_store_b64(v[i], rd, linear, i * step_l, AUX); }
   } else if (MODE == 2) {
 #pragma unroll
-    for (int i = 0; i < 16; i++) v[i] = __builtin_amdgcn_raw_buffer_load_b64(rs, linear, i * step_l, AUX);
+    for (int i = 0; i < E; i++) v[i] = __builtin_amdgcn_raw_buffer_load_b64(rs, linear, i * step_l, AUX);
 #pragma unroll
-    for (int i = 0; i < 16; i++) { v[i][0] += 1; __builtin_amdgcn_raw_buffer_store_b64(v[i], rd, strided, i * step_s, AUX); }
+    for (int i = 0; i < E; i++) { v[i][0] += 1; __builtin_amdgcn_raw_buffer_store_b64(v[i], rd, strided, i * step_s, AUX); }
   } else {
 #pragma unroll
-    for (int i = 0; i < 16; i++) v[i] = __builtin_amdgcn_raw_buffer_load_b64(rs, linear, i * step_l, AUX);
+    for (int i = 0; i < E; i++) v[i] = __builtin_amdgcn_raw_buffer_load_b64(rs, linear, i * step_l, AUX);
 #pragma unroll
-    for (int i = 0; i < 16; i++) { v[i][0] += 1; __builtin_amdgcn_raw_buffer_store_b64(v[i], rd, linear, i * step_l, AUX); }
+    for (int i = 0; i < E; i++) { v[i][0] += 1; __builtin_amdgcn_raw_buffer_store_b64(v[i], rd, linear, i * step_l, AUX); }
   }
 }
 
@@ -86,6 +87,10 @@ int main(int argc, char **argv)
     add<2, 8, 0, true>(lds_kb);
     add<2, 8, 2, true>(lds_kb);
   }
+  add<1, 16, 0, false>(150);
+  add<1, 16, 2, false>(150);
+  add<2, 16, 0, false>(150);
+  add<2, 16, 2, false>(150);
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (int i = 0; i < 50; i++) g_cfgs[0].launch();
   const int rounds = 7, reps = 6;
