@@ -44,7 +44,8 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t xform_rsrc(const float2 *base,
 // Cache policy of the two passes (aux of the buffer instructions, 2 = nt): the input streams in and the output streams
 // out without taking room in the 256 MiB Infinity Cache, the intermediate is written cacheable -- pass 2 finds part of it
 // there -- and read for the last time.  Same-box A/B against all-default: 2^22 x 8 0.272 -> 0.235 ms, 2^20 x 32 0.226 ->
-// 0.174, 2^16 x 1024 (512 MiB) 0.41 against 0.35 of the roofline, 2^22 x 64 (2 GiB) unchanged.
+// 0.174, 2^16 x 1024 (512 MiB) 0.41 against 0.35 of the roofline, 2^22 x 16 / x 32 0.281 / 0.280 against 0.261 / 0.273.
+// Beyond 1 GiB pass 2 of the 2^22-point transforms keeps the default policy both ways (POL = 1: 2^22 x 64 1.90 against 1.92 ms).
 constexpr int NT_L1 = 2, NT_S1 = 0, NT_L2 = 2, NT_S2 = 2;
 template <int AUX = 0>
 __device__ __forceinline__ float2 buf_load(const __amdgpu_buffer_rsrc_t &rs, uint32_t voff, uint32_t soff)
@@ -97,7 +98,7 @@ struct RowStore {
 //   XCD's L2 (tools/membench7: strided reads 4.0 -> 4.6 TB/s with it; strided writes lose 8 %, so MODE 2 maps plainly).
 // MODE 2: tile of the intermediate in -> * W_N^(row * column) -> FFT -> tile of the output out.  The twiddles are formed
 //   from the LDS copy of the three-level table while the tile's loads are in flight.
-template <bool INV>
+template <bool INV, int AUX>
 struct TileStore {
   static constexpr bool SPLIT = true;
   __amdgpu_buffer_rsrc_t rs;
@@ -106,13 +107,13 @@ struct TileStore {
   __device__ __forceinline__ void operator()(int t, int e0, int roff, float2 x) const
   {
     if (INV) x = make_float2(x.x * scale, -x.y * scale);
-    buf_store<NT_S2>(rs, ((uint32_t)e0 * other + c0 + (uint32_t)t) * 8u, (uint32_t)roff * other * 8u, x);
+    buf_store<AUX>(rs, ((uint32_t)e0 * other + c0 + (uint32_t)t) * 8u, (uint32_t)roff * other * 8u, x);
   }
 };
 
 // E = points per thread: 16 (tile = 16384 points, two workgroups per CU) or 32 (tile = 32768 points, one workgroup per CU;
 // used for 2048-point sub-transforms, where it doubles the strided side's runs from 64 to 128 bytes -- whole lines).
-template <int LOGA, int MODE, bool INV, bool TILED, int E>
+template <int LOGA, int MODE, bool INV, bool TILED, int E, int POL = 0>
 __global__ __launch_bounds__(1024, E == 16 ? 8 : 4) void fourstep_tile_kernel(const float2 *__restrict__ in, float2 *__restrict__ out,
                                                                             const float2 *__restrict__ tw,      // 2^LOGA-point table
                                                                             const float2 *__restrict__ tw_big,  // three-level table of W_N
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(1024, E == 16 ? 8 : 4) void fourstep_tile_kernel(co
   const uint32_t voff = (linear_in ? (tile << LOGTILE) + (uint32_t)tid : ((uint32_t)tid >> LOGC) * other + c0 + ((uint32_t)tid & (C - 1))) * 8u;
   const uint32_t step = linear_in ? 1024u * 8u : (1024u >> LOGC) * other * 8u;
 #pragma unroll
-  for (int i = 0; i < E; i++) v[(i % NB0) * R0 + i / NB0] = buf_load<(MODE == 1 ? NT_L1 : NT_L2)>(rs, voff, i * step);
+  for (int i = 0; i < E; i++) v[(i % NB0) * R0 + i / NB0] = buf_load<(MODE == 1 ? NT_L1 : (POL == 1 ? 0 : NT_L2))>(rs, voff, i * step);
   // The passes' twiddle bases are entries below A/2 of the A-point table: an LDS copy, so that no pass waits for a
   // global load queued behind the other resident workgroup's tile traffic (first read after the first exchange's barriers)
   float2 *big = reinterpret_cast<float2 *>(ldsf + IM::ELEMS);
@@ -209,12 +210,12 @@ __global__ __launch_bounds__(1024, E == 16 ? 8 : 4) void fourstep_tile_kernel(co
     RowStore<LOGA, TILED> st{ro, c0, log_other, log_blk};
     fft_block_split_il<PL, E == 16, E == 16, true>(v, ldsf, twl, tid, st);
   } else {
-    TileStore<INV> st{ro, other, c0, scale};
+    TileStore<INV, (POL == 1 ? 0 : NT_S2)> st{ro, other, c0, scale};
     fft_block_split_il<PL, E == 16, E == 16, true>(v, ldsf, twl, tid, st);
   }
 }
 
-template <int LOGA, int MODE, bool INV, bool TILED, int E>
+template <int LOGA, int MODE, bool INV, bool TILED, int E, int POL = 0>
 static hipError_t launch_pass(const float2 *in, float2 *out, const float2 *tw, const float2 *tw_big, int log_other, uint32_t batch,
                               int log_blk, float scale, hipStream_t stream)
 {
@@ -223,7 +224,7 @@ static hipError_t launch_pass(const float2 *in, float2 *out, const float2 *tw, c
   static std::atomic<bool> attr_done[16];  // zero-initialised; a racing second hipFuncSetAttribute is harmless
   int dev = 0;
   (void)hipGetDevice(&dev);
-  auto kern = fourstep_tile_kernel<LOGA, MODE, INV, TILED, E>;
+  auto kern = fourstep_tile_kernel<LOGA, MODE, INV, TILED, E, POL>;
   if (dev >= 16 || !attr_done[dev]) {
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
@@ -263,11 +264,24 @@ hipError_t launch_gen_twiddle_lo(float2 *tw, int logn, hipStream_t stream)
 // multiple of pass 2's tile width C2 = 16384 / N2, which holds for N1 >= 512, i.e. N >= 2^17:
 // pass 1 (LOGA = log2 N1) is blocked from LOGA = 9, pass 2 (LOGA = log2 N2) from LOGA = 9 and,
 // for N = 2^17 only, at LOGA = 8.
-// points per thread of the kernel that runs 2^loga-point sub-transforms (see fourstep_tile_kernel)
-static int tile_e(int loga) { return loga == 11 ? 32 : 16; }
+// points per thread of the kernel that runs 2^loga-point sub-transforms (see fourstep_tile_kernel): 32 only for 2048-point
+// sub-transforms, and there by measurement (2^22 points, same box):
+//   pass 1 (strided reads) wants the 128-byte runs of the 2048 x 16 tiles as soon as they fill the chip twice (batch 1: 128
+//   such tiles, 0.20 of the roofline against 0.225 with 2048 x 8 tiles);
+//   pass 2 reads the intermediate, part of which is still in the Infinity Cache while the whole job is small (see NT_*): up to
+//   2^25 points (256 MiB) two 2048 x 8 workgroups per CU overlap better than one 2048 x 16 (batch 4: 0.316 against 0.264,
+//   batch 8: 0.316 against 0.285, batch 12: equal), beyond that the longer runs of the strided writes win (batch 64: 0.279
+//   against 0.259).
+static int tile_e(int loga, int mode, int logn, uint32_t batch)
+{
+  if (loga != 11) return 16;
+  const uint64_t points = (uint64_t)batch << logn;
+  if (mode == 2) return points <= (1ull << 25) ? 16 : 32;
+  return (points >> 15) >= 512 ? 32 : 16;
+}
 
 template <int MODE, bool INV>
-static hipError_t launch_pass_log(int loga, const float2 *in, float2 *out, const float2 *tw, const float2 *tw_big, int log_other,
+static hipError_t launch_pass_log(int loga, int e32, const float2 *in, float2 *out, const float2 *tw, const float2 *tw_big, int log_other,
                                   uint32_t batch, int log_blk, float scale, bool tiled, hipStream_t stream)
 {
   switch (loga) {
@@ -276,7 +290,12 @@ static hipError_t launch_pass_log(int loga, const float2 *in, float2 *out, const
     case 8:
       if (MODE == 2 && tiled) return launch_pass<8, MODE, INV, (MODE == 2), 16>(in, out, tw, tw_big, log_other, batch, log_blk, scale, stream);
       return launch_pass<8, MODE, INV, false, 16>(in, out, tw, tw_big, log_other, batch, log_blk, scale, stream);
-    C(9, true, 16) C(10, true, 16) C(11, true, 32)
+    C(9, true, 16) C(10, true, 16)
+    case 11:
+      if (e32 && MODE == 2 && ((uint64_t)batch << (11 + log_other)) > (1ull << 27))  // beyond 1 GiB: default cache policy
+        return launch_pass<11, MODE, INV, true, 32, (MODE == 2 ? 1 : 0)>(in, out, tw, tw_big, log_other, batch, log_blk, scale, stream);
+      if (e32) return launch_pass<11, MODE, INV, true, 32>(in, out, tw, tw_big, log_other, batch, log_blk, scale, stream);
+      return launch_pass<11, MODE, INV, true, 16>(in, out, tw, tw_big, log_other, batch, log_blk, scale, stream);
 #undef C
   }
   return hipErrorInvalidValue;
@@ -290,16 +309,17 @@ hipError_t launch_cfft_large_f32(int logn, float2 *data, float2 *work, const flo
   const int log2_ = logn / 2, log1 = logn - log2_;  // N1 >= N2
   const float scale = 1.0f / (float)(1ull << logn);
   const bool tiled = logn >= 17;
-  const int log_blk = tile_e(log2_) == 32 ? 15 : 14;  // the block of the blocked intermediate = pass 2's tile
+  const int e1 = tile_e(log1, 1, logn, batch), e2 = tile_e(log2_, 2, logn, batch);
+  const int log_blk = e2 == 32 ? 15 : 14;  // the block of the blocked intermediate = pass 2's tile
   hipError_t e;
   if (!inverse) {
-    e = launch_pass_log<1, false>(log1, data, work, tw1, tw_big, log2_, batch, log_blk, 1.0f, tiled, stream);
+    e = launch_pass_log<1, false>(log1, e1 == 32, data, work, tw1, tw_big, log2_, batch, log_blk, 1.0f, tiled, stream);
     if (e != hipSuccess) return e;
-    return launch_pass_log<2, false>(log2_, work, data, tw2, tw_big, log1, batch, log_blk, 1.0f, tiled, stream);
+    return launch_pass_log<2, false>(log2_, e2 == 32, work, data, tw2, tw_big, log1, batch, log_blk, 1.0f, tiled, stream);
   }
-  e = launch_pass_log<1, true>(log1, data, work, tw1, tw_big, log2_, batch, log_blk, 1.0f, tiled, stream);
+  e = launch_pass_log<1, true>(log1, e1 == 32, data, work, tw1, tw_big, log2_, batch, log_blk, 1.0f, tiled, stream);
   if (e != hipSuccess) return e;
-  return launch_pass_log<2, true>(log2_, work, data, tw2, tw_big, log1, batch, log_blk, scale, tiled, stream);
+  return launch_pass_log<2, true>(log2_, e2 == 32, work, data, tw2, tw_big, log1, batch, log_blk, scale, tiled, stream);
 }
 
 }  // namespace armfft

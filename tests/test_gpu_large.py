@@ -103,6 +103,33 @@ def test_cfft_large_properties_full_size():
     assert float((y - x).double().norm() / x.double().norm()) < 1e-6
 
 
+@pytest.mark.parametrize("logn,batch", [(22, 12), (21, 8), (22, 4), (22, 34)])
+def test_cfft_large_tile_variants_agree(logn, batch):
+    """The 2048-point sub-transforms run on 2048 x 8 or 2048 x 16 tiles depending on pass and batch (tile_e in
+    armfft_large.hip): 2^22 x 12 = 2048 x 16 tiles in both passes (x 34, beyond 1 GiB: with pass 2's other cache policy), 2^22 x 4 and 2^21 x 8 mix them, batch 1 -- which
+    test_cfft_large_vs_f64 holds against the float64 oracle -- uses the small tiles.  Every row of the batch must match
+    its batch-1 transform to f32 rounding, forward and inverse."""
+    import torch
+    import fft_amd
+    import gpu_util as G
+    n = 1 << logn
+    S = fft_amd.arm_cfft_instance_u32_f32()
+    G.check(fft_amd.lib.arm_cfft_init_u32_f32(ctypes.byref(S), n))
+    g = torch.Generator(device="cuda").manual_seed(0x5EED0100 + logn + batch)
+    x = (torch.rand((batch, n, 2), device="cuda", generator=g) * 2 - 1).contiguous()
+    w = torch.empty_like(x)
+    for ifft in (0, 1):
+        y = x.clone()
+        G.check(fft_amd.lib.arm_cfft_u32_f32_dev(ctypes.byref(S), ctypes.c_void_p(y.data_ptr()), ctypes.c_void_p(w.data_ptr()), batch,
+                                                 ifft, G.stream_ptr()))
+        for b in (0, batch // 2, batch - 1):
+            z = x[b].clone()
+            G.check(fft_amd.lib.arm_cfft_u32_f32_dev(ctypes.byref(S), ctypes.c_void_p(z.data_ptr()), ctypes.c_void_p(w.data_ptr()), 1,
+                                                     ifft, G.stream_ptr()))
+            torch.cuda.synchronize()
+            assert float((y[b] - z).double().norm() / z.double().norm()) <= 5e-7
+
+
 def test_cfft_large_host_batch_and_errors():
     import fft_amd
     import torch
