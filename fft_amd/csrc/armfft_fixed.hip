@@ -507,6 +507,9 @@ struct DirectPlan {
   static constexpr int LDS_WORDS = N + (N >> SH);
   // 256 and 512 points take 16 / 32 threads: a one-wave workgroup holds 4 / 2 transforms, each with its own image
   static constexpr int TPB = T >= 64 ? 1 : 64 / T, WG = T * TPB;
+  // distance between the images of a workgroup's transforms: at four transforms (16 lanes each) = 16 mod 64 words, so that
+  // the same word of the four images falls into four different groups of 16 banks
+  static constexpr int IMG = LDS_WORDS + (TPB == 4 ? (64 + 16 - LDS_WORDS % 64) % 64 : 0);
   static __device__ __forceinline__ int pad(int p) { return p + (p >> SH); }
   // offset of point e0 + (c << LOGQ) from pad(e0): exact whenever those points stay inside one aligned block of
   // 2^(LOGQ+4) points that e0 starts with a remainder below 2^LOGQ (see the steps)
@@ -711,8 +714,8 @@ __global__ __launch_bounds__(DirectPlan<LOGN>::WG) void cfft_fixed_direct_kernel
   const uint32_t t0 = g * TPB;
   if (t0 >= batch) return;
   const int wtid = threadIdx.x, tid = wtid & (T - 1), tr = TPB == 1 ? 0 : wtid / T;
-  word *lds = reinterpret_cast<word *>(lds_raw) + tr * PL::LDS_WORDS;
-  tword *tl = reinterpret_cast<tword *>(reinterpret_cast<word *>(lds_raw) + TPB * PL::LDS_WORDS);
+  word *lds = reinterpret_cast<word *>(lds_raw) + tr * PL::IMG;
+  tword *tl = reinterpret_cast<tword *>(reinterpret_cast<word *>(lds_raw) + TPB * PL::IMG);
   // one descriptor over the group's valid transforms: loads past it read zeros, stores past it are dropped
   const uint32_t nvalid = batch - t0 < (uint32_t)TPB ? batch - t0 : (uint32_t)TPB;
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(data + (size_t)t0 * PL::N, 0, (int)(nvalid * PL::N * W), 0x00020000);
@@ -730,7 +733,7 @@ template <class Q, int LOGN, bool INV>
 static hipError_t launch_fixed_direct(typename Q::word *data, const typename Q::tword *tw, uint32_t batch, hipStream_t stream)
 {
   using PL = DirectPlan<LOGN>;
-  constexpr size_t lds_bytes = (size_t)PL::TPB * PL::LDS_WORDS * sizeof(typename Q::word) + (size_t)(3 * PL::N / 16) * sizeof(typename Q::tword);
+  constexpr size_t lds_bytes = (size_t)PL::TPB * PL::IMG * sizeof(typename Q::word) + (size_t)(3 * PL::N / 16) * sizeof(typename Q::tword);
   static_assert(lds_bytes <= 160 * 1024, "direct form: the transforms of a workgroup and the quarter table in LDS");
   static std::atomic<bool> attr_done[16];
   int dev = 0;
@@ -816,7 +819,7 @@ static hipError_t launch_fixed(int logn, typename Q::word *data, const typename 
   case L: return inverse ? launch_fixed_direct<Q, L, true>(data, tw, batch, stream) : launch_fixed_direct<Q, L, false>(data, tw, batch, stream);
       D(9) D(10) D(11) D(12) D(13) D(14)
 #undef D
-      case 8:  // 16 lanes per transform: 64-byte runs for q15 (0.61 against 0.72 of the roofline), 128-byte runs for q31 (0.705 against 0.63)
+      case 8:  // 16 lanes per transform: 64-byte runs for q15 (0.61 against 0.72 of the roofline), 128-byte runs for q31 (0.73 against 0.63)
         if (sizeof(typename Q::word) == 8)
           return inverse ? launch_fixed_direct<Q, 8, true>(data, tw, batch, stream) : launch_fixed_direct<Q, 8, false>(data, tw, batch, stream);
         break;
@@ -1084,8 +1087,8 @@ __global__ __launch_bounds__(DirectPlan<LOGN>::WG) void rfft_fixed_direct_kernel
   const uint32_t t0 = g * TPB;
   if (t0 >= batch) return;
   const int wtid = threadIdx.x, tid = wtid & (T - 1), tr = TPB == 1 ? 0 : wtid / T;
-  word *lds = reinterpret_cast<word *>(lds_raw) + tr * PL::LDS_WORDS;
-  tword *tl = reinterpret_cast<tword *>(reinterpret_cast<word *>(lds_raw) + TPB * PL::LDS_WORDS);
+  word *lds = reinterpret_cast<word *>(lds_raw) + tr * PL::IMG;
+  tword *tl = reinterpret_cast<tword *>(reinterpret_cast<word *>(lds_raw) + TPB * PL::IMG);
   const uint32_t nvalid = batch - t0 < (uint32_t)TPB ? batch - t0 : (uint32_t)TPB;
   cpx x[16];
   if (!INV) {
@@ -1133,7 +1136,7 @@ static hipError_t launch_rfft_fixed_direct(const typename Q::word *in, typename 
                                            const typename Q::tword *A, const typename Q::tword *B, int mod, uint32_t batch, hipStream_t stream)
 {
   using PL = DirectPlan<LOGN>;
-  constexpr size_t lds_bytes = (size_t)PL::TPB * PL::LDS_WORDS * sizeof(typename Q::word) + (size_t)(3 * PL::N / 16) * sizeof(typename Q::tword);
+  constexpr size_t lds_bytes = (size_t)PL::TPB * PL::IMG * sizeof(typename Q::word) + (size_t)(3 * PL::N / 16) * sizeof(typename Q::tword);
   static std::atomic<bool> attr_done[16];
   int dev = 0;
   (void)hipGetDevice(&dev);
