@@ -675,12 +675,12 @@ __global__ __launch_bounds__(GPlan<LOGN>::T, GPlan<LOGN>::T >= 1024 ? 4 : 3) voi
     });
     // (v_sqrt_f32: 1 ulp, no denormal rescue -- the magnitudes are O(1) after the 1/N scaling above)
     auto st = [&](int, int k, float2 y) { magl[mag_idx(k)] = __builtin_amdgcn_sqrtf(y.x * y.x + y.y * y.y); };
-    fft_block_preloaded<PL, true>(v, lds, twp, lt, st);
+    // (the previous row may still be read by the lane that parks it: the first pass waits before its first write)
+    fft_block_preloaded<PL, true, PL::NPASS - 1, true>(v, lds, twp, lt, st);
     __syncthreads();
     auto mag = [&](int m) -> float { return magl[mag_idx(m)]; };
     const Top2 t = top2_scan<T, 16, true>(mag, N, sep, lt, xch);
     park_row(pend, t, mag, N, p, lt);
-    __syncthreads();  // the row is dead: the next IFFT may overwrite it
     flush_rows(pend, N, p, n_prn, d, prns, all + (size_t)scene * n_prn * n_dop, n_dop, lt);
   }
 }

@@ -578,13 +578,15 @@ __device__ __forceinline__ void fft_block(float2 *lds, const float2 *__restrict_
 }
 
 // Same with the first pass's inputs already in v[16] (see Preloaded); hook runs in pass HP
-// (default: the last), see fft_pass.
-template <class PL, bool LDS_OUT, int HP = PL::NPASS - 1, class TW, class Store, class Hook = NoHook>
+// (default: the last), see fft_pass.  IMAGE_BUSY: other threads may still be reading the image when the call starts
+// (a previous result aliased to it): the first pass then puts a barrier between its butterflies and its first write, so
+// the caller needs none of its own and the first pass's arithmetic overlaps those readers.
+template <class PL, bool LDS_OUT, int HP = PL::NPASS - 1, bool IMAGE_BUSY = false, class TW, class Store, class Hook = NoHook>
 __device__ __forceinline__ void fft_block_preloaded(float2 *v, float2 *lds, const TW &tw, int tid, Store st, Hook hook = Hook())
 {
   Preloaded ld;
   float2 twa[PL::E - 1], twb[PL::E - 1];
-  PassLoop<PL, 0, false, LDS_OUT, HP, TW, Preloaded, Store, Hook>::run(v, lds, tw, tid, ld, st, twa, twb, hook);
+  PassLoop<PL, 0, IMAGE_BUSY, LDS_OUT, HP, TW, Preloaded, Store, Hook>::run(v, lds, tw, tid, ld, st, twa, twb, hook);
 }
 
 // ---- half-footprint exchange: real parts and imaginary parts cross the workgroup one after the other ----
