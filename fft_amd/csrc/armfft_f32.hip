@@ -388,7 +388,7 @@ __global__ __launch_bounds__(RPlan<LOGM>::T, RTune<LOGM>::MINW) void rfft_f32_ke
     for (int i = tid; i < PAIRS; i += PL::T) {
       const int e2 = 2 * i, t = e2 >> LOGM, e = e2 & (M - 1);
       float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-      if ((uint32_t)e2 < nvalid) x = *reinterpret_cast<const float4 *>(pi + e2);
+      if ((uint32_t)e2 < nvalid) { const f32x4 y = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(pi + e2)); x = make_float4(y[0], y[1], y[2], y[3]); }
       *reinterpret_cast<float4 *>(&lds[PL::idx(t, e)]) = x;
     }
     __syncthreads();
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(RPlan<LOGM>::T, RTune<LOGM>::MINW) void rfft_f32_ke
         o.z = 0.5f * (A1.x + B1.x + c4.z * a + c4.w * b);
         o.w = 0.5f * (A1.y - B1.y + c4.w * a - c4.z * b);
       }
-      *reinterpret_cast<float4 *>(po + e2) = o;
+      { f32x4 z; z[0] = o.x; z[1] = o.y; z[2] = o.z; z[3] = o.w; __builtin_nontemporal_store(z, reinterpret_cast<f32x4 *>(po + e2)); }
     }
     return;
   }
