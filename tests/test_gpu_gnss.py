@@ -236,7 +236,8 @@ def test_off_grid_scene_and_batch_of_scenes():
 
 
 @pytest.mark.parametrize("fft_len,spc,n_ms,prns,nd", [(1024, 1, 4, [1, 2, 3], 5), (2048, 2, 3, [4, 9, 21, 37], 7), (8192, 8, 2, [6, 30], 4),
-                                                      (16384, 16, 2, [12, 25], 3), (4096, 4, 1, [8], 1), (4096, 4, 64, [2, 3], 2)])
+                                                      (16384, 16, 2, [12, 25], 3), (4096, 4, 1, [8], 1), (4096, 4, 64, [2, 3], 2),
+                                                      (1024, 1, 2, list(range(1, 33)) * 2, 3)])   # 64 rows: the parked-row buffer exactly full
 def test_other_geometries(fft_len, spc, n_ms, prns, nd):
     spm = 1023 * spc
     svs = dict(prns=prns[:1], phases=[spm // 3], dopplers=[250.0])
