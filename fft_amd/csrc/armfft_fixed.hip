@@ -963,6 +963,11 @@ __global__ __launch_bounds__(FixedPlan<LOGN>::T, 4) void rfft_fixed_kernel(const
     for (int i = tid; i < 3 * PL::N / 16; i += PL::T) tl4[i] = tw[4 * i];
   }
 
+  // forward: the split's coefficients depend only on the thread (bins i0 .. i0 + SPER - 1 of step `it` of the store
+  // loop below): fetched here, behind the data loads
+  constexpr int SPER = (sizeof(word) == 8 || LOGN <= 9) ? 16 / sizeof(word) : 1, SITER = PL::ELEMS / SPER / PL::T;
+  static_assert(SITER * SPER == 16 && SITER * SPER * PL::T == PL::ELEMS, "16 bins per thread");
+  typename Q::tword ca[INV ? 1 : 16], cb[INV ? 1 : 16];
   // ---- load ----
   if (!INV) {
     const word *__restrict__ src = in + (size_t)tr0 * L;
@@ -974,6 +979,15 @@ __global__ __launch_bounds__(FixedPlan<LOGN>::T, 4) void rfft_fixed_kernel(const
       const word *pw = reinterpret_cast<const word *>(&raw);
 #pragma unroll
       for (int k = 0; k < PER16; k++) lds[fpad(e + k)] = pw[k];
+    }
+#pragma unroll
+    for (int it = 0; it < SITER; it++) {
+#pragma unroll
+      for (int k = 0; k < SPER; k++) {
+        const int i = (((tid + it * PL::T) * SPER) & (L - 1)) + k;
+        ca[INV ? 0 : it * SPER + k] = coefA[i * mod];
+        cb[INV ? 0 : it * SPER + k] = coefB[i * mod];
+      }
     }
   } else {
     for (int e = tid; e < PL::ELEMS; e += PL::T) {
@@ -1030,8 +1044,10 @@ __global__ __launch_bounds__(FixedPlan<LOGN>::T, 4) void rfft_fixed_kernel(const
     // word stores for the mirrored half (its run is offset by one word from 16-byte alignment)
     // (measured: pays for q31 and for q15 up to 1024 real points; larger q15 transforms lose 10 % to
     // the LDS conflicts of four bit-reversed reads per lane and keep one bin per lane)
-    constexpr int PER16 = (sizeof(word) == 8 || LOGN <= 9) ? 16 / sizeof(word) : 1;
-    for (int v = tid; v < PL::ELEMS / PER16; v += PL::T) {
+    constexpr int PER16 = SPER;
+#pragma unroll
+    for (int it = 0; it < SITER; it++) {
+      const int v = tid + it * PL::T;
       const int e = v * PER16, t = e >> LOGN, i0 = e & (L - 1);
       if ((uint32_t)t >= nvt) continue;
       word *__restrict__ d = dst + (size_t)t * (2 * L);
@@ -1045,7 +1061,7 @@ __global__ __launch_bounds__(FixedPlan<LOGN>::T, 4) void rfft_fixed_kernel(const
           pw[k] = Q::pack(dc_word(x0, false));
           d[L] = Q::pack(dc_word(x0, true));
         } else {
-          const cpx o = split_fwd(X(t, i), X(t, L - i), Q::unpack(coefA[i * mod]), Q::unpack(coefB[i * mod]));
+          const cpx o = split_fwd(X(t, i), X(t, L - i), Q::unpack(ca[INV ? 0 : it * SPER + k]), Q::unpack(cb[INV ? 0 : it * SPER + k]));
           pw[k] = Q::pack(o);
           d[2 * L - i] = Q::pack(mirror(o));
         }
