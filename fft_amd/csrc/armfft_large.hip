@@ -140,6 +140,12 @@ __global__ __launch_bounds__(1024, E == 16 ? 8 : 4) void fourstep_tile_kernel(co
   const uint32_t c0 = tile * C;
   // leg i of thread t: row t / C + i * 1024 / C, column c0 + t % C (or, from a blocked intermediate, element t + 1024 i of
   // the tile's contiguous block: the same element); butterfly q, leg r of the first pass is leg i = q + r * NB0
+  // Vector loads return in order: the two table entries a thread carries to LDS are requested BEFORE the tile, so that
+  // their copy -- and, in pass 2, the barrier behind it and the twiddle products -- does not wait for the tile's data.
+  static_assert(A / 2 <= 1024, "one table entry per thread");
+  float2 twl_r = make_float2(0.f, 0.f), big_r = make_float2(0.f, 0.f);
+  if (tid < A / 2) twl_r = tw[tid];
+  if (MODE == 2 && tid < kBigEntries) big_r = tw_big[tid];
   float2 v[E];
   const __amdgpu_buffer_rsrc_t rs = xform_rsrc(in + (size_t)xf * nfull, nfull);
   constexpr bool linear_in = (MODE == 2) && TILED;
@@ -151,8 +157,7 @@ __global__ __launch_bounds__(1024, E == 16 ? 8 : 4) void fourstep_tile_kernel(co
   // global load queued behind the other resident workgroup's tile traffic (first read after the first exchange's barriers)
   float2 *big = reinterpret_cast<float2 *>(ldsf + IM::ELEMS);
   float2 *twl = big + (MODE == 2 ? kBigEntries : 0);
-  static_assert(A / 2 <= 1024, "one table entry per thread");
-  if (tid < A / 2) twl[tid] = tw[tid];
+  if (tid < A / 2) twl[tid] = twl_r;
   if (MODE == 1) {
     if (INV) {
 #pragma unroll
@@ -161,7 +166,7 @@ __global__ __launch_bounds__(1024, E == 16 ? 8 : 4) void fourstep_tile_kernel(co
   } else {
     // B[row][col] *= W_N^(row * col): row = t / C + i * 1024 / C, col = c0 + t % C; the exponent advances by a constant
     // per leg and stays below N
-    if (tid < kBigEntries) big[tid] = tw_big[tid];
+    if (tid < kBigEntries) big[tid] = big_r;
     __syncthreads();
     const uint32_t col = c0 + ((uint32_t)tid & (C - 1));
     uint32_t m = ((uint32_t)tid >> LOGC) * col;
