@@ -717,6 +717,32 @@ __global__ __launch_bounds__(GPlan<LOGN>::T, 4) void gnss_group_spectra_kernel(c
   }
 }
 
+// Last-pass store of the accumulation kernel: output `slot` of the thread is y = conj(Y) / N of one group; MODE 1 adds |y|,
+// MODE 2 adds y conj(previous group's y) (mult / get_conj / add of gnss_codes.c:8-25) -- in registers, per slot.
+template <int MODE, int R>   // R = legs per butterfly of the last pass: slot = butterfly * R + leg
+struct AccStore {
+  static constexpr bool SPLIT = true;
+  static constexpr bool SLOT = true;
+  float *acc;
+  float2 *dacc, *prev;
+  float inv_n;
+  bool later;   // not the first group
+  __device__ __forceinline__ void operator()(int q, int r, int, int, int, float2 Y) const
+  {
+    const int slot = q * R + r;
+    const float2 y = make_float2(Y.x * inv_n, -Y.y * inv_n);
+    if (MODE == 1) {
+      acc[slot] += __builtin_amdgcn_sqrtf(y.x * y.x + y.y * y.y);
+    } else {
+      if (later) {
+        dacc[slot].x += y.x * prev[slot].x - y.y * (-prev[slot].y);
+        dacc[slot].y += y.x * (-prev[slot].y) + y.y * prev[slot].x;
+      }
+      prev[slot] = y;
+    }
+  }
+};
+
 // PRNs are taken kAccPrn at a time with the groups as the outer loop inside a chunk: a group's spectrum (32 KiB, from the
 // workspace = HBM / Infinity Cache) is loaded once per chunk instead of once per PRN and held in registers next to the
 // chunk's accumulators (per thread 16 code phases x kAccPrn PRNs).
@@ -745,7 +771,9 @@ __global__ __launch_bounds__(GPlan<LOGN>::T, GPlan<LOGN>::T >= 1024 ? 4 : 3) voi
   gnss_acq_result *rows = all + (size_t)scene * n_prn * n_dop;
   for (int p0 = 0; p0 < n_prn; p0 += P) {
     const int np = n_prn - p0 < P ? n_prn - p0 : P;
-    float acc[P][16];       // MODE 1: running sums of magnitudes of this thread's 16 code phases
+    // accumulators of the 16 code phases THIS thread's last pass produces (slot order of the transform): a group's row
+    // never goes through LDS, only the accumulated row does, once per PRN
+    float acc[P][16];       // MODE 1: running sums of magnitudes
     float2 dacc[MODE == 2 ? P : 1][16], prev[MODE == 2 ? P : 1][16];
 #pragma unroll
     for (int pi = 0; pi < P; pi++) {
@@ -776,24 +804,10 @@ __global__ __launch_bounds__(GPlan<LOGN>::T, GPlan<LOGN>::T >= 1024 ? 4 : 3) voi
             const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(cs, j * 8, roff * 8, 0);
             v[slot] = cmul(zr[slot], make_float2(__uint_as_float(w[0]), __uint_as_float(w[1])));
           });
-          // forward FFT of conj(Z) C = conj(y) * N: the row is written as y (conjugated back, scaled)
-          auto st = [&](int, int k, float2 y) { lds[PL::idx(0, k)] = make_float2(y.x * inv_n, -y.y * inv_n); };
-          fft_block_preloaded<PL, true>(v, lds, twp, lt, st);
-          __syncthreads();
-#pragma unroll
-          for (int c = 0; c < 16; c++) {
-            const float2 y = lds[PL::idx(0, m0 + c)];
-            if (MODE == 1) {
-              acc[pi][c] += __builtin_amdgcn_sqrtf(y.x * y.x + y.y * y.y);
-            } else {
-              if (g > 0) {  // diff_acc += y * conj(prev)   (mult / get_conj / add of gnss_codes.c:8-25)
-                dacc[pi][c].x += y.x * prev[pi][c].x - y.y * (-prev[pi][c].y);
-                dacc[pi][c].y += y.x * (-prev[pi][c].y) + y.y * prev[pi][c].x;
-              }
-              prev[pi][c] = y;
-            }
-          }
-          __syncthreads();  // the row is consumed: the next IFFT may overwrite it
+          // forward FFT of conj(Z) C = conj(y) * N: y = the output conjugated back and scaled
+          AccStore<MODE, (1 << PL::lr(PL::NPASS - 1))> st{acc[pi], dacc[MODE == 2 ? pi : 0], prev[MODE == 2 ? pi : 0], inv_n, g > 0};
+          // (the image may still be read by another wave's last pass of the previous transform: IMAGE_BUSY)
+          fft_block_preloaded<PL, false, PL::NPASS - 1, true>(v, lds, twp, lt, st);
         }
       }
     }
@@ -801,14 +815,15 @@ __global__ __launch_bounds__(GPlan<LOGN>::T, GPlan<LOGN>::T >= 1024 ? 4 : 3) voi
     for (int pi = 0; pi < P; pi++) {
       if (pi < np) {
         const int p = p0 + pi;
-#pragma unroll
-        for (int c = 0; c < 16; c++)
-          magl[mag_idx(m0 + c)] = (MODE == 1) ? acc[pi][c] : sqrtf(dacc[pi][c].x * dacc[pi][c].x + dacc[pi][c].y * dacc[pi][c].y);
+        __syncthreads();  // the image (the last transform's reads, or the previous row's scan) is free
+        for_each_last_pass_output<PL>(tid, [&](int slot, int, int e0, int roff) {
+          magl[mag_idx(e0 + roff)] =
+              (MODE == 1) ? acc[pi][slot] : sqrtf(dacc[MODE == 2 ? pi : 0][slot].x * dacc[MODE == 2 ? pi : 0][slot].x + dacc[MODE == 2 ? pi : 0][slot].y * dacc[MODE == 2 ? pi : 0][slot].y);
+        });
         __syncthreads();
         auto mag = [&](int m) -> float { return magl[mag_idx(m)]; };
         const Top2 t = top2_scan<T, 16, true>(mag, N, sep, tid, xch);
         park_row(pend, t, mag, N, p, tid);
-        __syncthreads();
         flush_rows(pend, N, p, n_prn, d, prns, rows, n_dop, tid);
       }
     }
