@@ -1,8 +1,13 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MI355X-native CMSIS FFT hot path.
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Started plainly with --gpus N > 1 (no WORLD_SIZE in the environment) the process launches the second form itself, as a
+child, BEFORE it imports torch or touches a GPU, relays rank 0's JSON line and exits with the child's status; it refuses
+(non-zero exit, message) when fewer than N GPUs are visible.  Started under torch.distributed.run, --gpus must equal
+WORLD_SIZE: a mismatch is refused instead of printing one GPU's number under another n_gpus.
 
 One "step" = one pass of the hot path over one batch of synthetic input: the BASELINE.json
 configs[1] workload, `arm_cfft_f32` forward, 4096 points x 65536 transforms, in place, resident in
@@ -19,10 +24,14 @@ Extra objects on that line:
                   the SURVEY 8(d) table: 1 core and all cores, the -O2 build and the -O3 AVX2 build of
                   oracle/_ref, streaming (distinct buffers) and cache-resident (one 32 KiB buffer),
                   each the median of 5 repeats.
-  extra        -- (N = 1 only) the other BASELINE.json configs measured the same way in the same run,
-                  a few steps each: cfft_q15 / cfft_q31 4096x65536, rfft_f32 16384x16384, the four-step
-                  2^22 x 8 and GNSS acquisition x256; each entry carries value, ms_per_step and its own
-                  roofline object.  The headline `value` / `roofline` stay those of config 2.
+  extra        -- the other BASELINE.json configs measured the same way in the same run, a few steps each, on
+                  EVERY rank (batches / scenes per GPU, barrier + max over ranks like the headline): cfft_q15 /
+                  cfft_q31 4096x65536, rfft_f32 16384x16384, the four-step 2^22 x 8 (config 4) and x 64 (beyond the
+                  Infinity Cache), GNSS acquisition x256 scenes per GPU (config 5) and, with more than one rank, config 5
+                  sharded the other way: Doppler bins per GPU + the all-gather of the winners, checked against the
+                  single-rank search (`merged_equals_single_rank_search`).  Each entry carries value, ms_per_step,
+                  the slowest and fastest rank's step time and its own roofline object.  The headline `value` /
+                  `roofline` stay those of config 2.
 
 `--workload gnss_acq_gps_l1_x256 --gnss-shard doppler` times the OTHER way the GNSS search shards
 (SURVEY 8e): every rank holds all scenes, searches its share of the 41 Doppler bins
@@ -326,7 +335,7 @@ def build_workload(name, wl, rank, stream, dop_range=None):
     kind, n, batch = w.kind, w.n, w.batch
     gen = torch.Generator(device="cuda").manual_seed(0x5EED0001 + rank)
     vp = ctypes.c_void_p
-    w.rescale, w.chunk, w.out, w.extra_config = None, 1 << 30, None, {}
+    w.rescale, w.chunk, w.out, w.extra_config, w.kernel_name = None, 1 << 30, None, {}, ""
     if kind == "f32":
         S = fft_amd.arm_cfft_instance_f32()
         assert lib.arm_cfft_init_f32(ctypes.byref(S), n) == 0
@@ -341,7 +350,6 @@ def build_workload(name, wl, rank, stream, dop_range=None):
         w.step = lambda: lib.arm_cfft_f32_dev(ctypes.byref(S), vp(data.data_ptr()), batch, 0, 1, stream)
         w.rescale = lambda p: data.mul_(2.0 ** (-(growth * p) / 2.0)).mul_(2.0 ** (-(growth * p) / 2.0))   # p passes of growth, exact powers of two
         w.bytes_per_xform, w.flops_per_xform = 16 * n, 5.0 * n * np.log2(n)
-        w.kernel_name = "cfft_f32_kernel<%d, false>" % int(np.log2(n))
         w.data = data
     elif kind == "large":
         S = fft_amd.arm_cfft_instance_u32_f32()
@@ -353,7 +361,6 @@ def build_workload(name, wl, rank, stream, dop_range=None):
         w.rescale = lambda p: data.mul_(2.0 ** (-(int(np.log2(n)) / 2.0) * p))
         # algorithmic bytes per SURVEY 8(d): 16*N per transform; the four-step moves every point twice
         w.bytes_per_xform, w.flops_per_xform = 16 * n, 5.0 * n * np.log2(n)
-        w.kernel_name = "fourstep_pass_kernel<%d|%d, 1|2, false> (two launches per step)" % ((int(np.log2(n)) + 1) // 2, int(np.log2(n)) // 2)
         w.data, w.work = data, work
     elif kind == "gnss":
         n_ms, spc, spm = 10, 4, 4092
@@ -388,7 +395,6 @@ def build_workload(name, wl, rank, stream, dop_range=None):
         # "transform" = one scene; flops at 5NlogN per FFT: one forward per Doppler bin + one inverse per (PRN, bin)
         w.flops_per_xform = (len(dops) + w.rows_per_scene) * 5.0 * n * np.log2(n)
         w.bytes_per_xform = nn * 8 + w.rows_per_scene * 32                      # compulsory HBM bytes: signal in, tuples out
-        w.kernel_name = "gnss_acquire_kernel<12>"
         w.data, w.cells, w.best, w.plan = data, cells, best, plan
         w.extra_config = {"prns": 32, "doppler_bins": 41, "coherent_ms": 10, "scenes_per_gpu": batch}
     elif kind in ("rq15", "rq31"):
@@ -402,7 +408,6 @@ def build_workload(name, wl, rank, stream, dop_range=None):
         w.step = lambda: fn(ctypes.byref(S), vp(data.data_ptr()), vp(out.data_ptr()), batch, stream)
         sz = 2 if q == "q15" else 4
         w.bytes_per_xform, w.flops_per_xform = 3 * n * sz, 2.5 * n * np.log2(n)      # n scalars in, 2n scalars out (spectrum + mirror)
-        w.kernel_name = "rfft_fixed_kernel<%s, %d, false>" % (q.upper(), int(np.log2(n)) - 1)
         w.data, w.out = data, out
     elif kind in ("q15", "q31"):
         S = (fft_amd.arm_cfft_instance_q15 if kind == "q15" else fft_amd.arm_cfft_instance_q31)()
@@ -412,7 +417,6 @@ def build_workload(name, wl, rank, stream, dop_range=None):
         fn = getattr(lib, "arm_cfft_%s_dev" % kind)
         w.step = lambda: fn(ctypes.byref(S), vp(data.data_ptr()), batch, 0, 1, stream)   # fixed point scales itself by 1/N per pass
         w.bytes_per_xform, w.flops_per_xform = (8 if kind == "q15" else 16) * n, 5.0 * n * np.log2(n)
-        w.kernel_name = "cfft_fixed_kernel<%s, %d, false>" % (kind.upper(), int(np.log2(n)))
         w.data = data
     else:
         S = fft_amd.arm_rfft_fast_instance_f32()
@@ -421,36 +425,99 @@ def build_workload(name, wl, rank, stream, dop_range=None):
         out = torch.empty_like(data)
         w.step = lambda: lib.arm_rfft_fast_f32_dev(ctypes.byref(S), vp(data.data_ptr()), vp(out.data_ptr()), batch, 0, stream)
         w.bytes_per_xform, w.flops_per_xform = 8 * n, 2.5 * n * np.log2(n)
-        w.kernel_name = "rfft_f32_kernel<%d, false>" % (int(np.log2(n)) - 1)
         w.data, w.out = data, out
     w.inst = S if kind != "gnss" else None   # keeps the ctypes instance alive as long as the step closure
     return w
 
 
-def preheat(w, ms, state, ev0, ev1):
-    """Untimed launches of the workload's own step for `ms` milliseconds of wall time (see --preheat-ms); returns the count."""
-    import torch
+class _EventTimer:
+    """HIP events on the launch stream (torch's current stream = the one handed to the _dev calls)."""
+    def __init__(self):
+        import torch
+        self.ev0, self.ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def start(self):
+        self.ev0.record()
+
+    def stop(self):
+        self.ev1.record()
+
+    def elapsed_ms(self):
+        self.ev1.synchronize()
+        return self.ev0.elapsed_time(self.ev1)
+
+
+class _WallTimer:
+    """The same interface on the host clock: the step loop of this file under gloo on the CPU (tests/dist_worker.py)."""
+    def start(self):
+        self.t0 = time.perf_counter()
+
+    def stop(self):
+        self.t1 = time.perf_counter()
+
+    def elapsed_ms(self):
+        return 1e3 * (self.t1 - self.t0)
+
+
+class Ctx:
+    """Where a measurement runs: rank / world, the device synchronisation, the timer, the collectives."""
+    def __init__(self, rank=0, world=1, use_dist=False, device="cuda", stream=None):
+        self.rank, self.world, self.use_dist, self.device, self.stream = rank, world, use_dist, device, stream
+
+    def sync(self):
+        if self.device == "cuda":
+            import torch
+            torch.cuda.synchronize()
+
+    def timer(self):
+        return _EventTimer() if self.device == "cuda" else _WallTimer()
+
+    def barrier(self):
+        if self.use_dist:
+            import torch.distributed as dist
+            dist.barrier()
+        self.sync()
+
+    def minmax(self, vals):
+        """(min over ranks, max over ranks) of a list of floats"""
+        if not self.use_dist:
+            return list(vals), list(vals)
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor(list(vals) + [-v for v in vals], device=self.device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t = t.tolist()
+        k = len(vals)
+        return [-v for v in t[k:]], t[:k]
+
+
+def preheat(w, ms, state, ctx):
+    """Untimed launches for `ms` milliseconds of wall time (see --preheat-ms); returns the count.  The loop runs on each
+    rank's OWN clock, so the ranks make different numbers of passes: it therefore runs w.local_step -- the workload's
+    kernels WITHOUT any collective (for the Doppler-sharded GNSS step: the rank's own search, no all-gather) -- or the
+    ranks' collective counts would drift apart and a later barrier pair with somebody's all-gather."""
     n, t_end = 0, time.perf_counter() + ms / 1e3
     while ms > 0 and time.perf_counter() < t_end:
-        run_steps(w, 4, False, state, ev0, ev1)
-        torch.cuda.synchronize()
+        run_steps(w, 4, False, state, None, local=True)
+        ctx.sync()
         n += 4
     return n
 
 
-def run_steps(w, m, timed, state, ev0, ev1):
-    """m passes of w.step(); timed: HIP events on the launch stream around the launches (the rescale that keeps
-    f32 data finite stays outside the events, inside the caller's wall clock)."""
+def run_steps(w, m, timed, state, timer, local=False):
+    """m passes of w.step() (local: w.local_step, the collective-free form); timed: the timer brackets the launches (the
+    rescale that keeps f32 data finite stays outside it, inside the caller's wall clock)."""
     import fft_amd
+    step = getattr(w, "local_step", w.step) if local else w.step
     state.setdefault("since", 0)   # passes since the data were last scaled back
     while m > 0:
         todo = min(m, w.chunk - state["since"]) if w.rescale else m
         if timed:
-            ev0.record()
+            timer.start()
         for _ in range(todo):
-            assert w.step() == 0, fft_amd.last_error()
+            assert step() == 0, fft_amd.last_error()
         if timed:
-            ev1.record()
+            timer.stop()
         state["passes"] += todo
         state["since"] += todo
         m -= todo
@@ -458,8 +525,26 @@ def run_steps(w, m, timed, state, ev0, ev1):
             w.rescale(state["since"])
             state["since"] = 0
         if timed:
-            ev1.synchronize()
-            state["kernel_ms"] += ev0.elapsed_time(ev1)
+            state["kernel_ms"] += timer.elapsed_ms()
+
+
+def timed_region(w, K, W, preheat_ms, ctx):
+    """The contract's measurement of one workload: [barrier] preheat (collective-free), W warm-up steps, barrier + sync,
+    EXACTLY K timed steps, barrier + sync; elapsed = MAX over ranks.  Every rank runs the same number of w.step() calls,
+    so a step may hold a collective."""
+    state = {"passes": 0, "kernel_ms": 0.0}
+    timer = ctx.timer()
+    ctx.barrier()                      # the ranks finish building their workloads at different times
+    n_pre = preheat(w, preheat_ms, state, ctx)
+    run_steps(w, W, False, state, timer)
+    settle_scale(w, K, state)
+    ctx.barrier()
+    t0 = time.perf_counter()
+    run_steps(w, K, True, state, timer)
+    ctx.barrier()
+    elapsed = time.perf_counter() - t0
+    lo, hi = ctx.minmax([elapsed, state["kernel_ms"]])
+    return {"elapsed": hi[0], "elapsed_min": lo[0], "kernel_ms": hi[1], "kernel_ms_min": lo[1], "n_pre": n_pre}
 
 
 def settle_scale(w, k, state):
@@ -487,55 +572,174 @@ def roofline_of(w, launch_s, traffic_table):
             "avg_launch_ms": round(1e3 * launch_s, 4)}
 
 
-EXTRA_WORKLOADS = ["cfft_q15_4096x65536", "cfft_q31_4096x65536", "rfft_f32_16384x16384", "cfft_f32_4194304x8", "gnss_acq_gps_l1_x256"]
+EXTRA_WORKLOADS = ["cfft_q15_4096x65536", "cfft_q31_4096x65536", "rfft_f32_16384x16384", "cfft_f32_4194304x8", "cfft_f32_4194304x64",
+                   "gnss_acq_gps_l1_x256"]
 
 
-def measure_extra(name, steps, stream, traffic_table, preheat_ms=50.0):
-    """One of the other BASELINE configs, measured like the headline (HIP events on the launch stream, wall clock
-    around them), a few steps, memory released afterwards."""
+def make_doppler_sharded(w, ctx):
+    """Turn a GNSS workload into the Doppler-sharded step: one step = this rank's Doppler bins of every scene
+    + ONE all-gather of the winners (fft_amd.dist.sharded_acquire, the function tests/test_dist_cpu.py drives over gloo);
+    the tuples live on the device the process group works on.  w.local_step stays the rank's own search, no collective."""
+    import numpy as np
     import torch
-    wl = resolve_workload(name)
-    w = build_workload(name, wl, 0, stream)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    state = {"passes": 0, "kernel_ms": 0.0}
-    n_pre = preheat(w, preheat_ms, state, ev0, ev1)
-    run_steps(w, 2, False, state, ev0, ev1)
-    settle_scale(w, steps, state)
+
+    import fft_amd
+    from fft_amd import dist as D
+
+    rows = w.batch * w.n_prn
+    row_prns = torch.as_tensor(np.tile(w.prns, w.batch), dtype=torch.int32, device="cuda")
+    d0, d1 = D.doppler_range(w.n_dop, ctx.rank, ctx.world)
+    w.merged = None
+
+    def acquire(a, b):
+        assert w.acquire(a, b) == 0, fft_amd.last_error()
+        return w.best.view(rows, 8)
+
+    def step_sharded():
+        w.merged, _ = D.sharded_acquire(acquire, w.n_dop, rows, ctx.rank, ctx.world, row_prns=row_prns, device="cuda")
+        return 0
+
+    w.local_step = (lambda: w.acquire(d0, d1)) if d1 > d0 else (lambda: 0)
+    w.step = step_sharded
+    return w
+
+
+def check_doppler_merge(w, ctx):
+    """Outside the timed region: the merged tuples must equal this rank's own search of ALL bins, on every rank."""
+    import torch
+    import torch.distributed as dist
+
+    import fft_amd
+    assert w.acquire(0, w.n_dop) == 0, fft_amd.last_error()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run_steps(w, steps, True, state, ev0, ev1)
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    launch_s = state["kernel_ms"] / 1e3 / steps
+    ok = bool(torch.equal(w.merged, w.best.view(w.batch * w.n_prn, 8)))
+    if ctx.use_dist:
+        f = torch.tensor([1.0 if ok else 0.0], device="cuda")
+        dist.all_reduce(f, op=dist.ReduceOp.MIN)
+        ok = bool(f.item() == 1.0)
+    assert ok, "Doppler-sharded search + merge differs from the single-rank search of all bins"
+    return ok
+
+
+def measure(name, wl, K, W, preheat_ms, ctx, traffic_table, shard_doppler=False):
+    """One workload measured by the contract on every rank of ctx (each rank its own batch / scenes, or -- GNSS with
+    shard_doppler -- every rank all scenes and its share of the Doppler bins).  Returns (result dict, workload)."""
+    import torch
+
+    import fft_amd
+    from fft_amd import dist as D
+    from fft_amd import lib
+
+    dop_range = D.doppler_range(41, ctx.rank, ctx.world) if shard_doppler else None
+    w = build_workload(name, wl, ctx.rank, ctx.stream, dop_range=dop_range)
+    if shard_doppler:
+        make_doppler_sharded(w, ctx)
+    t = timed_region(w, K, W, preheat_ms, ctx)
+    w.kernel_name = lib.arm_fft_mi355_last_kernel().decode()        # the plan actually launched, as rocprofv3 spells it
+    elapsed, launch_s = t["elapsed"], t["kernel_ms"] / 1e3 / K
+    world = ctx.world
+    finite = True
+    if w.kind in ("f32", "rfft", "large"):
+        finite = bool(torch.isfinite(w.out if w.kind == "rfft" else w.data).all())
+    merge_ok = check_doppler_merge(w, ctx) if shard_doppler else None
     if w.kind == "gnss":
-        metric, value, unit = "GNSS acquisition cells/s (PRN x Doppler bin x code phase)", round(w.batch * steps * 32 * 41 * 4096 / elapsed, 1), "cells/s"
+        scenes_total = w.batch * K * (1 if shard_doppler else world)
+        metric, value, unit = "GNSS acquisition cells/s (PRN x Doppler bin x code phase)", round(scenes_total * 32 * 41 * 4096 / elapsed, 1), "cells/s"
     else:
-        metric, value, unit = name + " GFLOP/s (5NlogN; real: 2.5NlogN)", round(w.batch * steps * w.flops_per_xform / elapsed / 1e9, 2), "GFLOP/s"
-    out = {"workload": name, "metric": metric, "value": value, "unit": unit, "steps": steps, "warmup": 2, "preheat_launches": n_pre, "ms_per_step": round(1e3 * elapsed / steps, 4),
-           "dtype": w.dtype, "roofline": roofline_of(w, launch_s, traffic_table)}
+        gflops = w.batch * K * world * w.flops_per_xform / elapsed / 1e9
+        metric, value, unit = name + " GFLOP/s (5NlogN; real: 2.5NlogN)", round(gflops, 2), "GFLOP/s"
+    res = {"workload": name, "metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": K, "warmup": W, "preheat_launches": t["n_pre"],
+           "ms_per_step": round(1e3 * elapsed / K, 4),
+           "ms_per_step_ranks": {"min": round(1e3 * t["elapsed_min"] / K, 4), "max": round(1e3 * elapsed / K, 4)},
+           "scaling": "strong" if shard_doppler else "weak", "dtype": w.dtype, "output_finite": finite}
+    if shard_doppler:
+        # the events bracket kernels AND the all-gather here: report the step time, not a kernel roofline of a partial search
+        res["roofline"] = roofline_of(w, launch_s, {})
+        res["roofline"]["note"] = "avg_launch_ms spans this rank's share of the Doppler bins plus the all-gather of the winners"
+        res["sharding"] = ("Doppler bins per GPU (41 bins over %d ranks), scenes replicated, one all-gather of %d x 32-byte tuples per step"
+                           % (world, w.batch * w.n_prn))
+        res["merged_equals_single_rank_search"] = merge_ok
+    else:
+        res["roofline"] = roofline_of(w, launch_s, traffic_table)
+        res["sharding"] = ("scenes" if w.kind == "gnss" else "independent batches") + " per GPU, no collective"
+    res["roofline"]["avg_launch_ms_ranks"] = {"min": round(t["kernel_ms_min"] / K, 4), "max": round(t["kernel_ms"] / K, 4)}
+    return res, w
+
+
+def release(w):
+    import torch
+    from fft_amd import lib
     if w.kind == "gnss":
-        from fft_amd import lib
         lib.gnss_acq_plan_destroy(w.plan)
-    del w
+    w.__dict__.clear()
     torch.cuda.empty_cache()
-    return out
+
+
+def visible_gpus():
+    """Number of GPUs torch would see, counted in a CHILD process: this process must stay clear of the HIP runtime until
+    it has decided whether to become the launcher (a process that initialised the GPU must not start others through exec)."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True, timeout=300)
+        return int(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 and r.stdout.strip() else 0
+    except Exception:
+        return 0
+
+
+def launch_ranks(args):
+    """--gpus N > 1 without a torch.distributed.run environment: start it ourselves (fresh child, one rank per GPU, RCCL
+    rendezvous on 127.0.0.1), relay rank 0's JSON line, return the child's status."""
+    import socket
+    import subprocess
+    have = visible_gpus()
+    if have < args.gpus:
+        sys.stderr.write("bench.py: --gpus %d asked for, %d GPU(s) visible on this node: refusing to run (a smaller run would "
+                         "print a line that claims n_gpus=%d)\n" % (args.gpus, have, args.gpus))
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    for ln in r.stdout.splitlines():
+        if not ln.startswith("{"):
+            sys.stderr.write(ln + "\n")
+    if lines:
+        print(lines[-1], flush=True)
+    elif r.returncode == 0:
+        sys.stderr.write("bench.py: the ranks exited cleanly but printed no result line\n")
+        return 3
+    return r.returncode
 
 
 def main():
     args = parse()
-    import numpy as np
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if env_world is None and args.gpus > 1:
+        sys.exit(launch_ranks(args))
+    if env_world is not None and int(env_world) != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%s: refusing to print one configuration's number under another's n_gpus "
+                         "(launch with --nproc-per-node equal to --gpus)" % (args.gpus, env_world))
+
     import torch
     import torch.distributed as dist
 
     import fft_amd
     from fft_amd import lib
-    from fft_amd import dist as D
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(env_world or "1")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: fft_amd has no CPU path")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d has no GPU (LOCAL_RANK %d, %d visible)" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or args.force_dist   # --force-dist: the RCCL group, barrier, reductions and all-gather with ONE rank too
     if use_dist:
@@ -544,123 +748,74 @@ def main():
 
     wl = resolve_workload(args.workload, args.batch)
     K, W = args.steps, args.warmup
-    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ctx = Ctx(rank, world, use_dist, "cuda", ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     shard_doppler = wl["kind"] == "gnss" and args.gnss_shard == "doppler"
-    w = build_workload(args.workload, wl, rank, stream, dop_range=D.doppler_range(41, rank, world) if shard_doppler else None)
+    traffic_table = {}
+    tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(tp):
+        try:
+            traffic_table = json.load(open(tp))
+        except Exception:
+            traffic_table = {}
+
+    head, w = measure(args.workload, wl, K, W, args.preheat_ms, ctx, traffic_table, shard_doppler)
     kind, n, batch = w.kind, w.n, w.batch
-    merged = None
+    extra_config = dict(w.extra_config)
+    release(w)
+
+    if args.workload == "cfft_f32_4096x65536":
+        metric = "batched cfft_f32 4096-pt GFLOP/s (5NlogN) + % HBM roofline; GNSS acq cells/s"
+    elif kind == "gnss":
+        metric = head["metric"]
+    else:
+        metric = args.workload + " GFLOP/s"
+    line = {
+        "metric": metric,
+        "value": head["value"],
+        "unit": head["unit"],
+        "n_gpus": world,
+        "steps": K,
+        "warmup": W,
+        "ms_per_step": head["ms_per_step"],
+        "ms_per_step_ranks": head["ms_per_step_ranks"],
+        "higher_is_better": True,
+        "scaling": head["scaling"],
+        "vs_baseline": None,
+        "dtype": head["dtype"],
+        "data": "synthetic",
+        "config": {"workload": args.workload, "fft_len": n, "batch_per_gpu": batch, "direction": "forward",
+                   "in_place": kind != "rfft", "sharding": head["sharding"],
+                   "output_finite": head["output_finite"],
+                   "preheat": "%d untimed launches (%.0f ms of wall time) before the %d warm-up steps, so that the timed steps see the "
+                              "settled clocks of a sustained run (--preheat-ms 0 disables)" % (head["preheat_launches"], args.preheat_ms, W)},
+        "roofline": head["roofline"],
+    }
+    if kind == "gnss":
+        line["config"].update(extra_config)
     if shard_doppler:
-        # one step = this rank's Doppler bins of every scene + ONE all-gather of the winners (fft_amd.dist.sharded_acquire,
-        # the function tests/test_dist_cpu.py drives over gloo); the tuples live on the device the process group works on
-        rows = batch * w.n_prn
-        row_prns = torch.as_tensor(np.tile(w.prns, batch), dtype=torch.int32, device="cuda")
+        line["config"]["merged_equals_single_rank_search"] = head["merged_equals_single_rank_search"]
 
-        def acquire(a, b):
-            assert w.acquire(a, b) == 0, fft_amd.last_error()
-            return w.best.view(rows, 8)
-
-        def step_sharded():
-            nonlocal merged
-            merged, _ = D.sharded_acquire(acquire, w.n_dop, rows, rank, world, row_prns=row_prns, device="cuda")
-            return 0
-        w.step = step_sharded
-
-    def barrier():
+    if not args.no_extra and args.workload == "cfft_f32_4096x65536" and not args.batch:
+        # the other configs, measured in this same run on every rank (the headline's memory was released first)
+        extra = []
+        for nm in EXTRA_WORKLOADS:
+            res, wx = measure(nm, resolve_workload(nm), args.extra_steps, 2, args.preheat_ms / 2, ctx, traffic_table)
+            release(wx)
+            extra.append(res)
         if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    ev0 = torch.cuda.Event(enable_timing=True)
-    ev1 = torch.cuda.Event(enable_timing=True)
-    state = {"passes": 0, "kernel_ms": 0.0}
-    n_pre = preheat(w, args.preheat_ms, state, ev0, ev1)
-    run_steps(w, W, False, state, ev0, ev1)
-    settle_scale(w, K, state)
-    barrier()
-    t0 = time.perf_counter()
-    run_steps(w, K, True, state, ev0, ev1)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    kernel_ms = state["kernel_ms"]
-
-    if use_dist:
-        t = torch.tensor([elapsed, kernel_ms], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, kernel_ms = float(t[0]), float(t[1])
-
-    finite = True
-    if kind in ("f32", "rfft", "large"):
-        finite = bool(torch.isfinite(w.out if kind == "rfft" else w.data).all())
-    merge_ok = None
-    if shard_doppler:
-        # outside the timed region: the merged tuples must equal this rank's own search of ALL bins
-        assert w.acquire(0, w.n_dop) == 0, fft_amd.last_error()
-        torch.cuda.synchronize()
-        merge_ok = bool(torch.equal(merged, w.best.view(batch * w.n_prn, 8)))
-        if use_dist:
-            f = torch.tensor([1.0 if merge_ok else 0.0], device="cuda")
-            dist.all_reduce(f, op=dist.ReduceOp.MIN)
-            merge_ok = bool(f.item() == 1.0)
-        assert merge_ok, "Doppler-sharded search + merge differs from the single-rank search of all bins"
-
+            # config 5 the other way: every rank all 256 scenes, its share of the 41 Doppler bins, one all-gather per step
+            res, wx = measure("gnss_acq_gps_l1_x256", resolve_workload("gnss_acq_gps_l1_x256"), args.extra_steps, 2, args.preheat_ms / 2, ctx, {},
+                              shard_doppler=True)
+            release(wx)
+            res["workload"] = "gnss_acq_gps_l1_x256 (Doppler-sharded)"
+            extra.append(res)
+        line["extra"] = extra
     if rank == 0:
-        traffic_table = {}
-        tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tp):
-            try:
-                traffic_table = json.load(open(tp))
-            except Exception:
-                traffic_table = {}
-        scenes_total = batch * K * (1 if shard_doppler else world)
-        total_xforms = batch * K * world
-        gflops = total_xforms * w.flops_per_xform / elapsed / 1e9
-        launch_s = kernel_ms / 1e3 / K
-        if kind == "gnss":
-            metric, value, unit = "GNSS acquisition cells/s (PRN x Doppler bin x code phase)", round(scenes_total * 32 * 41 * 4096 / elapsed, 1), "cells/s"
-        elif args.workload == "cfft_f32_4096x65536":
-            metric, value, unit = "batched cfft_f32 4096-pt GFLOP/s (5NlogN) + % HBM roofline; GNSS acq cells/s", round(gflops, 2), "GFLOP/s"
-        else:
-            metric, value, unit = args.workload + " GFLOP/s", round(gflops, 2), "GFLOP/s"
-        line = {
-            "metric": metric,
-            "value": value,
-            "unit": unit,
-            "n_gpus": world,
-            "steps": K,
-            "warmup": W,
-            "ms_per_step": round(1e3 * elapsed / K, 4),
-            "higher_is_better": True,
-            "scaling": "strong" if shard_doppler else "weak",
-            "vs_baseline": None,
-            "dtype": w.dtype,
-            "data": "synthetic",
-            "config": {"workload": args.workload, "fft_len": n, "batch_per_gpu": batch, "direction": "forward",
-                       "in_place": kind != "rfft", "sharding": "independent batches per GPU, no collective",
-                       "output_finite": finite,
-                       "preheat": "%d untimed launches (%.0f ms of wall time) before the %d warm-up steps, so that the timed steps see the "
-                                  "settled clocks of a sustained run (--preheat-ms 0 disables)" % (n_pre, args.preheat_ms, W)},
-        }
-        if shard_doppler:
-            # the events bracket kernels AND the all-gather here: report the step time, not a kernel roofline of a partial search
-            line["roofline"] = roofline_of(w, launch_s, {})
-            line["roofline"]["note"] = "avg_launch_ms spans this rank's share of the Doppler bins plus the all-gather of the winners"
-            line["config"].update(w.extra_config)
-            line["config"].update({"sharding": "Doppler bins per GPU (41 bins over %d ranks), scenes replicated, one all-gather of %d x 32-byte tuples per step"
-                                               % (world, batch * w.n_prn), "merged_equals_single_rank_search": merge_ok})
-        else:
-            line["roofline"] = roofline_of(w, launch_s, traffic_table)
-            if kind == "gnss":
-                line["config"].update(w.extra_config)
-                line["config"]["sharding"] = "scenes per GPU, no collective"
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(kind, n, args.cpu_seconds)
-        if world == 1 and not args.no_extra and args.workload == "cfft_f32_4096x65536" and not args.batch:
-            # the other configs, measured in this same run (the headline's memory is released first)
-            del w
-            torch.cuda.empty_cache()
-            line["extra"] = [measure_extra(nm, args.extra_steps, stream, traffic_table, args.preheat_ms / 2) for nm in EXTRA_WORKLOADS]
         print(json.dumps(line), flush=True)
     if use_dist:
+        dist.barrier()
         dist.destroy_process_group()
 
 

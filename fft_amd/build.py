@@ -1,6 +1,6 @@
 """Build libarmfft_mi355.so (hipcc, gfx950 only) in-tree: fft_amd/lib/libarmfft_mi355.so.
 
-Usage: python -m fft_amd.build [--force]
+Usage: python fft_amd/build.py [--force]   (by path: importing the package would load a stale or missing library)
 The .so is git-ignored but travels to the GPU box with the tree (see .gpurunignore rules).
 """
 import os
@@ -33,8 +33,16 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def _compile(src):
+def _headers():
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hpp"))]
+    return hs + [os.path.join(HERE, "..", "include", "arm_fft_mi355.h")]
+
+
+def _compile(src, force=False):
+    """One object per source; recompiled only when the source or a header is newer than it."""
     obj = os.path.join(OBJDIR, src + ".o")
+    if not force and not _stale(obj, [os.path.join(CSRC, src)] + _headers()):
+        return obj
     cmd = [HIPCC] + FLAGS + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
     subprocess.run(cmd, check=True)
     return obj
@@ -43,13 +51,15 @@ def _compile(src):
 def build(force=False, verbose=True):
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     if not force and not _stale(LIB, _deps()):
+        if verbose:
+            print("[fft_amd.build] %s is up to date, not rebuilt (--force rebuilds)" % os.path.relpath(LIB), flush=True)
         return LIB
     os.makedirs(OBJDIR, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
     if verbose:
         print("[fft_amd.build] hipcc gfx950:", " ".join(srcs), flush=True)
     with ThreadPoolExecutor(max_workers=4) as ex:
-        objs = list(ex.map(_compile, srcs))
+        objs = list(ex.map(lambda f: _compile(f, force), srcs))
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     subprocess.run(cmd, check=True)
     return LIB

@@ -114,9 +114,10 @@ EXPORTED_SYMBOLS = (
     + ["up_sample_N_to_M", "up_sample_10k_to_16k", "iq_resamp_zero_phase_dev", "iq_resamp_zero_phase_count"]
     + ["write_bb_msb", "read_bb_msb", "gnss_acq_to_meas", "gnss_acq_plan_create_replicas", "gnss_l5_generate_I_dev"]
     + ["gnss_e1b_cboc_replica_dev", "gnss_hexstream_to_chips", "gnss_acquire_multi"]
+    + ["gnss_mix_prn_dev", "gnss_make_replica_dev", "gnss_rotate_fwd_dev", "mix_prn", "make_replica", "rotate_fwd"]
     + ["getCode", "synth_gps_prn", "find_top2_peaks_cplx", "find_top2_peaks_real", "compute_snr_cplx", "compute_snr_real", "InterpolateCodePhase"]
     + ["iq_resamp_zp_init", "iq_resamp_process_zero_phase", "iq_resamp_zp_free"]
-    + ["arm_fft_mi355_set_device", "arm_fft_mi355_warm", "arm_fft_mi355_last_error",
+    + ["arm_fft_mi355_set_device", "arm_fft_mi355_warm", "arm_fft_mi355_last_error", "arm_fft_mi355_last_kernel",
        "arm_fft_mi355_set_twiddle_rounding", "arm_fft_mi355_version"]
 )
 
@@ -125,7 +126,7 @@ def _load():
     path = lib_path()
     if not os.path.exists(path):
         raise ImportError(
-            "%s is missing: build it with `python -m fft_amd.build` (hipcc, gfx950). "
+            "%s is missing: build it with `python fft_amd/build.py` (hipcc, gfx950). "
             "fft_amd has no CPU fallback." % path)
     # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64.so.7.  If torch is going to
     # be used in this process (tests, bench: device memory and streams) it must be loaded FIRST so
@@ -219,6 +220,12 @@ def _load():
     sz = ctypes.c_size_t
     L.getCode.argtypes, L.getCode.restype = [c_int, c_int, c_int, c_void_p], None
     L.synth_gps_prn.argtypes, L.synth_gps_prn.restype = [c_int, c_float, sz, c_void_p, c_int], None
+    L.gnss_mix_prn_dev.argtypes, L.gnss_mix_prn_dev.restype = [c_void_p, dbl, dbl, c_void_p, u32, i32, c_void_p], c_int
+    L.gnss_make_replica_dev.argtypes, L.gnss_make_replica_dev.restype = [c_void_p, u32, c_float, c_float, c_void_p, c_void_p], c_int
+    L.gnss_rotate_fwd_dev.argtypes, L.gnss_rotate_fwd_dev.restype = [c_void_p, c_void_p, u32, i32, c_void_p], c_int
+    L.mix_prn.argtypes, L.mix_prn.restype = [c_void_p, dbl, dbl, c_void_p, c_int, c_int], None
+    L.make_replica.argtypes, L.make_replica.restype = [c_void_p, c_void_p, c_float, c_int, c_float], None
+    L.rotate_fwd.argtypes, L.rotate_fwd.restype = [c_void_p, c_int, c_int], None
     for nm in ("find_top2_peaks_cplx", "find_top2_peaks_real"):
         f = getattr(L, nm)
         f.argtypes, f.restype = [c_void_p, c_int, c_int, POINTER(top2_pks), c_void_p], c_int
@@ -232,6 +239,7 @@ def _load():
     L.arm_fft_mi355_set_device.argtypes, L.arm_fft_mi355_set_device.restype = [c_int], c_int
     L.arm_fft_mi355_warm.argtypes, L.arm_fft_mi355_warm.restype = [c_int, u32], c_int
     L.arm_fft_mi355_last_error.argtypes, L.arm_fft_mi355_last_error.restype = [], c_char_p
+    L.arm_fft_mi355_last_kernel.argtypes, L.arm_fft_mi355_last_kernel.restype = [], c_char_p
     L.arm_fft_mi355_set_twiddle_rounding.argtypes, L.arm_fft_mi355_set_twiddle_rounding.restype = [c_int], c_int
     L.arm_fft_mi355_version.argtypes, L.arm_fft_mi355_version.restype = [], c_char_p
     return L

@@ -32,6 +32,22 @@ void set_error(const char *fmt, ...)
   fprintf(stderr, "libarmfft_mi355: %s\n", t_err);
 }
 
+// last kernel(s) launched by this thread: two (format, arguments) records, formatted when asked for
+struct KernelNote {
+  const char *fmt = nullptr;
+  int a[5] = {0, 0, 0, 0, 0};
+};
+static thread_local KernelNote t_note[2];
+static thread_local char t_note_text[320] = "";
+
+void note_kernel(const char *fmt, bool append, int a, int b, int c, int d, int e)
+{
+  KernelNote &n = t_note[append ? 1 : 0];
+  n.fmt = fmt;
+  n.a[0] = a; n.a[1] = b; n.a[2] = c; n.a[3] = d; n.a[4] = e;
+  if (!append) t_note[1].fmt = nullptr;
+}
+
 bool hip_ok(hipError_t e, const char *what)
 {
   if (e == hipSuccess) return true;
@@ -44,14 +60,15 @@ bool hip_ok(hipError_t e, const char *what)
 // constant blob Source/CommonTables/arm_common_tables.c; here they are generated once per size:
 //   f32  twiddle[2i] = cos(2 pi i/N), [2i+1] = sin(2 pi i/N)            (arm_common_tables.h:63-84)
 //   rfft twiddle[2i] = sin(2 pi i/N), [2i+1] = cos(2 pi i/N), i < N/2   (:151-165)
-//   q15/q31: 3N/4 (cos, sin) pairs * 2^15 / 2^31, +1.0 saturated; rounding floor (default) or
-//            nearest -- arm_fft_mi355_set_twiddle_rounding                (:88-130)
+//   q15/q31: 3N/4 (cos, sin) pairs * 2^15 / 2^31, +1.0 saturated; rule per arm_fft_mi355_set_twiddle_rounding:
+//            0 floor, 1 nearest (both on the double value), 2 the fork's own generator (CMSIS/CMSIS.cpp:445-458
+//            + :309-327), 3 (default) = floor up to 4096 points, the fork's generator at 8192 / 16384 (:88-130)
 //   f32 bit-reversal index table: swap pairs (byte offsets) realising the radix-(2|4),8,8.. digit
 //            reversal, same format arm_bitreversal_32 consumes (arm_bitreversal2.c:84-108)
 //   fixed-point index table: plain bit-reversal swap pairs (arm_bitreversal2.c:123-148)
 // ------------------------------------------------------------------------------------------
 static std::mutex g_mu;
-static int g_tw_rounding = 0;
+static int g_tw_rounding = 3;   // 3 = per size: see effective_rounding()
 
 struct HostTables {
   std::vector<float> tw_f32, tw_rfft;
@@ -61,10 +78,15 @@ struct HostTables {
 };
 static HostTables g_host[kMaxLog + 2];
 
-static int tw_rounding()
+// The rule a size's table is made by.  Mode 3 (default): the sizes the reference's tests cover (16 ... 4096) keep floor --
+// the fork's generator misses the reference's own q31 bound there (tests/test_oracle_golden.py), so those tables were not
+// printed by it; 8192 and 16384 are the fork's additions and its generator is the only rule the mount holds for them.
+static int effective_rounding(int mode, int logn) { return mode == 3 ? (logn >= 13 ? 2 : 0) : mode; }
+
+static int tw_rounding(int logn)
 {
   std::lock_guard<std::mutex> lk(g_mu);
-  return g_tw_rounding;
+  return effective_rounding(g_tw_rounding, logn);
 }
 
 static int ilog2u(uint32_t n)
@@ -96,6 +118,29 @@ static int64_t to_fixed(double v, double scale, int rounding, int64_t lo, int64_
   if (r > (double)hi) r = (double)hi;
   if (r < (double)lo) r = (double)lo;
   return (int64_t)r;
+}
+
+// Rule 2, the fork's own generator: twiddleCoefCalculator (CMSIS/CMSIS.cpp:445-458) feeds to_fixed (:309-327).
+//   float c = cos(i * 2 * PI / (float)fft_len) with the FLOAT literal PI (Include/gnss_codes.h:33): int i*2, float product,
+//   float division; cos / sin of that float, stored to float; to_fixed: float product with (float)pow(2, dyad), llround,
+//   clamp (b > max -> max, b <= min -> min; the constants carry the q15 values in comments: swapped with the dyad),
+//   negatives b = ~abs(b) = one lower than the rounded value.  No exact values at multiples of pi/2.
+static void fork_cs(uint32_t i, uint32_t N, float *c, float *s)
+{
+  volatile float num = (float)(int)(i * 2u) * 3.14159265358979f;   // volatile: the two float roundings stay two
+  volatile float arg = num / (float)N;
+  *c = (float)cos((double)arg);
+  *s = (float)sin((double)arg);
+}
+static int64_t fork_to_fixed(float f, int dyad, int64_t lo, int64_t hi)
+{
+  const float tmp = (float)pow(2.0f, dyad);
+  volatile float prod = f * tmp;
+  int64_t b = (int64_t)llround((double)prod);
+  if (b > 0 && b > hi) return hi;
+  if (b < 0 && b <= lo) return lo;
+  if (b < 0) b = ~(-b);
+  return b;
 }
 
 static uint32_t brev(uint32_t v, int bits)
@@ -156,11 +201,19 @@ static const int16_t *host_tw_q15(int logn)
   if (t.empty()) {
     uint32_t N = 1u << logn;
     t.resize(3 * N / 2);
+    const int rule = effective_rounding(g_tw_rounding, logn);
     for (uint32_t i = 0; i < 3 * N / 4; i++) {
+      if (rule == 2) {
+        float c, s;
+        fork_cs(i, N, &c, &s);
+        t[2 * i] = (int16_t)fork_to_fixed(c, 15, -32768, 32767);
+        t[2 * i + 1] = (int16_t)fork_to_fixed(s, 15, -32768, 32767);
+        continue;
+      }
       double c, s;
       exact_cs(i, N, &c, &s);
-      t[2 * i] = (int16_t)to_fixed(c, 32768.0, g_tw_rounding, -32768, 32767);
-      t[2 * i + 1] = (int16_t)to_fixed(s, 32768.0, g_tw_rounding, -32768, 32767);
+      t[2 * i] = (int16_t)to_fixed(c, 32768.0, rule, -32768, 32767);
+      t[2 * i + 1] = (int16_t)to_fixed(s, 32768.0, rule, -32768, 32767);
     }
   }
   return t.data();
@@ -173,11 +226,19 @@ static const int32_t *host_tw_q31(int logn)
   if (t.empty()) {
     uint32_t N = 1u << logn;
     t.resize(3 * N / 2);
+    const int rule = effective_rounding(g_tw_rounding, logn);
     for (uint32_t i = 0; i < 3 * N / 4; i++) {
+      if (rule == 2) {
+        float c, s;
+        fork_cs(i, N, &c, &s);
+        t[2 * i] = (int32_t)fork_to_fixed(c, 31, INT32_MIN, INT32_MAX);
+        t[2 * i + 1] = (int32_t)fork_to_fixed(s, 31, INT32_MIN, INT32_MAX);
+        continue;
+      }
       double c, s;
       exact_cs(i, N, &c, &s);
-      t[2 * i] = (int32_t)to_fixed(c, 2147483648.0, g_tw_rounding, INT32_MIN, INT32_MAX);
-      t[2 * i + 1] = (int32_t)to_fixed(s, 2147483648.0, g_tw_rounding, INT32_MIN, INT32_MAX);
+      t[2 * i] = (int32_t)to_fixed(c, 2147483648.0, rule, INT32_MIN, INT32_MAX);
+      t[2 * i + 1] = (int32_t)to_fixed(s, 2147483648.0, rule, INT32_MIN, INT32_MAX);
     }
   }
   return t.data();
@@ -323,6 +384,15 @@ static bool aligned16(const void *p, const char *fn)
   return false;
 }
 
+// inverse arm_rfft_q15 / _q31: a transform's input is n + 2 scalars (68 bytes for 32 q15 points), read point by point, so a
+// caller that slices a batch lands on word boundaries only: the kernels need the point's own alignment, not 16 bytes
+static bool aligned_to(const void *p, unsigned bytes, const char *fn)
+{
+  if (((uintptr_t)p & (uintptr_t)(bytes - 1)) == 0) return true;
+  set_error("%s: device pointer %p is not %u-byte aligned", fn, p, bytes);
+  return false;
+}
+
 static bool current_device(int *dev)
 {
   // the device count cannot change during the life of the process: ask once (a launch otherwise pays
@@ -447,7 +517,7 @@ static const int16_t *dev_tw_q15(int logn)
   if (!current_device(&dev)) return nullptr;
   if (int16_t *q = slot_peek(g_dev[dev].tw_q15[logn])) return q;
   const int16_t *host = host_tw_q15(logn);
-  const int rounding = tw_rounding();
+  const int rounding = tw_rounding(logn);
   std::lock_guard<std::mutex> lk(g_dev_mu);
   return dev_tw_fixed<int16_t>(g_dev[dev].tw_q15[logn], logn, host, launch_gen_twiddle_q15, rounding);
 }
@@ -458,7 +528,7 @@ static const int32_t *dev_tw_q31(int logn)
   if (!current_device(&dev)) return nullptr;
   if (int32_t *q = slot_peek(g_dev[dev].tw_q31[logn])) return q;
   const int32_t *host = host_tw_q31(logn);
-  const int rounding = tw_rounding();
+  const int rounding = tw_rounding(logn);
   std::lock_guard<std::mutex> lk(g_dev_mu);
   return dev_tw_fixed<int32_t>(g_dev[dev].tw_q31[logn], logn, host, launch_gen_twiddle_q31, rounding);
 }
@@ -579,6 +649,24 @@ extern "C" {
 const char *arm_fft_mi355_version(void) { return "armfft_mi355 0.1 (gfx950)"; }
 const char *arm_fft_mi355_last_error(void) { return t_err; }
 
+const char *arm_fft_mi355_last_kernel(void)
+{
+  size_t used = 0;
+  t_note_text[0] = 0;
+  for (int i = 0; i < 2; i++) {
+    const KernelNote &n = t_note[i];
+    if (!n.fmt || used + 8 >= sizeof t_note_text) continue;
+    if (i && used) used += (size_t)snprintf(t_note_text + used, sizeof t_note_text - used, " + ");
+#pragma GCC diagnostic push
+#pragma GCC diagnostic ignored "-Wformat-nonliteral"
+#pragma GCC diagnostic ignored "-Wformat-security"
+    int w = snprintf(t_note_text + used, sizeof t_note_text - used, n.fmt, n.a[0], n.a[1], n.a[2], n.a[3], n.a[4]);
+#pragma GCC diagnostic pop
+    if (w > 0) used = (used + (size_t)w < sizeof t_note_text) ? used + (size_t)w : sizeof t_note_text - 1;
+  }
+  return t_note_text;
+}
+
 arm_status arm_fft_mi355_set_device(int device)
 {
   return hip_ok(hipSetDevice(device), "hipSetDevice") ? ARM_MATH_SUCCESS : ARM_MATH_ARGUMENT_ERROR;
@@ -592,7 +680,11 @@ arm_status arm_fft_mi355_set_twiddle_rounding(int mode)
       set_error("twiddle rounding must be chosen before the first fixed-point init");
       return ARM_MATH_ARGUMENT_ERROR;
     }
-  g_tw_rounding = mode ? 1 : 0;
+  if (mode < 0 || mode > 3) {
+    set_error("twiddle rounding mode %d: 0 floor, 1 nearest, 2 the fork's generator, 3 per size (default)", mode);
+    return ARM_MATH_ARGUMENT_ERROR;
+  }
+  g_tw_rounding = mode;
   return ARM_MATH_SUCCESS;
 }
 
@@ -765,7 +857,8 @@ ARMFFT_RFIX_INIT_N(1024) ARMFFT_RFIX_INIT_N(2048) ARMFFT_RFIX_INIT_N(4096) ARMFF
 arm_status arm_rfft_q15_dev(const arm_rfft_instance_q15 *S, const q15_t *pSrc, q15_t *pDst, uint32_t batch, void *stream)
 {
   if (!S || !pSrc || !pDst) { set_error("arm_rfft_q15_dev: null argument"); return ARM_MATH_ARGUMENT_ERROR; }
-  if (!aligned16(pSrc, "arm_rfft_q15_dev") || !aligned16(pDst, "arm_rfft_q15_dev")) return ARM_MATH_ARGUMENT_ERROR;
+  if (!(S->ifftFlagR ? aligned_to(pSrc, 4, "arm_rfft_q15_dev") : aligned16(pSrc, "arm_rfft_q15_dev")) || !aligned16(pDst, "arm_rfft_q15_dev"))
+    return ARM_MATH_ARGUMENT_ERROR;
   const int l = rfft_fixed_log(S->fftLenReal);
   if (l < 0) { set_error("arm_rfft_q15_dev: unsupported fftLenReal %u", S->fftLenReal); return ARM_MATH_ARGUMENT_ERROR; }
   const int16_t *tw = dev_tw_q15(l - 1), *rc = dev_rc15(l);
@@ -777,7 +870,8 @@ arm_status arm_rfft_q15_dev(const arm_rfft_instance_q15 *S, const q15_t *pSrc, q
 arm_status arm_rfft_q31_dev(const arm_rfft_instance_q31 *S, const q31_t *pSrc, q31_t *pDst, uint32_t batch, void *stream)
 {
   if (!S || !pSrc || !pDst) { set_error("arm_rfft_q31_dev: null argument"); return ARM_MATH_ARGUMENT_ERROR; }
-  if (!aligned16(pSrc, "arm_rfft_q31_dev") || !aligned16(pDst, "arm_rfft_q31_dev")) return ARM_MATH_ARGUMENT_ERROR;
+  if (!(S->ifftFlagR ? aligned_to(pSrc, 8, "arm_rfft_q31_dev") : aligned16(pSrc, "arm_rfft_q31_dev")) || !aligned16(pDst, "arm_rfft_q31_dev"))
+    return ARM_MATH_ARGUMENT_ERROR;
   const int l = rfft_fixed_log(S->fftLenReal);
   if (l < 0) { set_error("arm_rfft_q31_dev: unsupported fftLenReal %u", S->fftLenReal); return ARM_MATH_ARGUMENT_ERROR; }
   const int32_t *tw = dev_tw_q31(l - 1), *rc = dev_rc31(l);

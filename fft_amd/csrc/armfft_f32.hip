@@ -540,14 +540,15 @@ static hipError_t launch_cfft_one(float2 *data, const float2 *tw, uint32_t batch
   if constexpr (Tune<LOGN>::SPLIT) {
     static std::atomic<bool> split_attr_done[16];
     const size_t lds = SplitImage<PL>::LDS_BYTES;
-    if (lds > 48 * 1024 && dev < 16 && !split_attr_done[dev]) {
+    if (lds > 48 * 1024 && (dev < 0 || dev >= 16 || !split_attr_done[dev])) {   // beyond the cache's 16 slots: set it every time
       hipError_t e = hipFuncSetAttribute((const void *)cfft_f32_split_kernel<LOGN, INV, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e == hipSuccess) e = hipFuncSetAttribute((const void *)cfft_f32_split_kernel<LOGN, INV, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e == hipSuccess) e = hipFuncSetAttribute((const void *)cfft_f32_split_kernel<LOGN, INV, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
-      split_attr_done[dev] = true;
+      if (dev >= 0 && dev < 16) split_attr_done[dev] = true;
     }
     const dim3 grid = grid_for(batch);
+    note_kernel(INV ? "cfft_f32_split_kernel<%d, true, %d>" : "cfft_f32_split_kernel<%d, false, %d>", false, LOGN, order);
     if (order == 0) cfft_f32_split_kernel<LOGN, INV, 0><<<grid, PL::T, lds, stream>>>(data, tw, batch);
     else if (order == 1) cfft_f32_split_kernel<LOGN, INV, 1><<<grid, PL::T, lds, stream>>>(data, tw, batch);
     else cfft_f32_split_kernel<LOGN, INV, 2><<<grid, PL::T, lds, stream>>>(data, tw, batch);
@@ -555,13 +556,14 @@ static hipError_t launch_cfft_one(float2 *data, const float2 *tw, uint32_t batch
   }
   auto kern = cfft_f32_kernel<LOGN, INV>;
   const size_t lds_bytes = cfft_lds_bytes<LOGN>();
-  if (lds_bytes > 48 * 1024 && dev < 16 && !attr_done[dev]) {
+  if (lds_bytes > 48 * 1024 && (dev < 0 || dev >= 16 || !attr_done[dev])) {
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
-    attr_done[dev] = true;
+    if (dev >= 0 && dev < 16) attr_done[dev] = true;
   }
   const uint32_t ngroups = (batch + PL::TPB - 1) / PL::TPB;
   dim3 grid = grid_for(ngroups);
+  note_kernel(INV ? "cfft_f32_kernel<%d, true>" : "cfft_f32_kernel<%d, false>", false, LOGN);
   kern<<<grid, PL::T, lds_bytes, stream>>>(data, tw, batch, ngroups, order);
   return hipGetLastError();
 }
@@ -588,13 +590,14 @@ static hipError_t launch_rfft_one(const float2 *in, float2 *out, const float2 *t
   int dev = 0;
   (void)hipGetDevice(&dev);
   auto kern = rfft_f32_kernel<LOGM, INV>;
-  if (PL::LDS_BYTES > 48 * 1024 && dev < 16 && !attr_done[dev]) {
+  if (PL::LDS_BYTES > 48 * 1024 && (dev < 0 || dev >= 16 || !attr_done[dev])) {
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PL::LDS_BYTES);
     if (e != hipSuccess) return e;
-    attr_done[dev] = true;
+    if (dev >= 0 && dev < 16) attr_done[dev] = true;
   }
   const uint32_t ngroups = (batch + PL::TPB - 1) / PL::TPB;
   dim3 grid = grid_for(ngroups);
+  note_kernel(INV ? "rfft_f32_kernel<%d, true>" : "rfft_f32_kernel<%d, false>", false, LOGM);
   kern<<<grid, PL::T, PL::LDS_BYTES, stream>>>(in, out, tw, twr, batch, ngroups);
   return hipGetLastError();
 }

@@ -729,6 +729,11 @@ __global__ __launch_bounds__(DirectPlan<LOGN>::WG) void cfft_fixed_direct_kernel
   for (int c = 0; c < 16; c++) DirectIo<Q>::store(Q::pack(direct_out<Q, LOGN>(x[c])), rs, voff, direct_rc(c) * T * W);
 }
 
+// rocprof's spelling of a fixed-point kernel instance, for note_kernel (Q15 packs a point into one 32-bit word)
+#define ARMFFT_KNAME_Q(base)                                                                                                   \
+  (sizeof(typename Q::word) == 4 ? (INV ? base "<armfft::Q15, %d, true>" : base "<armfft::Q15, %d, false>")                     \
+                                 : (INV ? base "<armfft::Q31, %d, true>" : base "<armfft::Q31, %d, false>"))
+
 template <class Q, int LOGN, bool INV>
 static hipError_t launch_fixed_direct(typename Q::word *data, const typename Q::tword *tw, uint32_t batch, hipStream_t stream)
 {
@@ -746,6 +751,7 @@ static hipError_t launch_fixed_direct(typename Q::word *data, const typename Q::
   }
   const uint32_t groups = (batch + PL::TPB - 1) / PL::TPB;
   const uint32_t gx = groups < 65536u ? groups : 65536u, gy = (groups + gx - 1) / gx;
+  note_kernel(ARMFFT_KNAME_Q("cfft_fixed_direct_kernel"), false, LOGN);
   kern<<<dim3(gx, gy, 1), PL::WG, lds_bytes, stream>>>(data, tw, batch);
   return hipGetLastError();
 }
@@ -757,6 +763,26 @@ __global__ void gen_twiddle_fixed_kernel(T *tw, uint32_t n, int rounding)
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= 3 * n / 4) return;
   double s, c;
+  if (rounding == 2) {
+    // the fork's own generator (CMSIS/CMSIS.cpp:445-458 twiddleCoefCalculator + :309-327 to_fixed): float angle
+    // (i*2)*PIf / (float)N, cos/sin of that float stored to float, FLOAT product with 2^dyad, round half away, clamps,
+    // negatives one lower (b = ~|b|).  n is a power of two, so the float division is an exact scaling.
+    const float num = __fmul_rn((float)(int)(i * 2u), 3.14159265358979f);
+    const float arg = __fdiv_rn(num, (float)n);
+    const float cf = (float)cos((double)arg), sf = (float)sin((double)arg);
+    const float scale_f = sizeof(T) == 2 ? 32768.0f : 2147483648.0f;
+    const long long hi = sizeof(T) == 2 ? 32767ll : 2147483647ll, lo = sizeof(T) == 2 ? -32768ll : -2147483648ll;
+    long long b[2] = {llround((double)__fmul_rn(cf, scale_f)), llround((double)__fmul_rn(sf, scale_f))};
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      long long v = b[k];
+      if (v > 0 && v > hi) v = hi;
+      else if (v < 0 && v <= lo) v = lo;
+      else if (v < 0) v = ~(-v);
+      tw[2 * i + k] = (T)v;
+    }
+    return;
+  }
   if ((4u * i) % n == 0) {
     const uint32_t q = (4u * i / n) & 3u;
     c = (q == 0) ? 1.0 : ((q == 2) ? -1.0 : 0.0);
@@ -797,13 +823,14 @@ static hipError_t launch_fixed_one(typename Q::word *data, const typename Q::two
   int dev = 0;
   (void)hipGetDevice(&dev);
   auto kern = cfft_fixed_kernel<Q, LOGN, INV>;
-  if (lds_bytes > 48 * 1024 && dev < 16 && !attr_done[dev]) {
+  if (lds_bytes > 48 * 1024 && (dev < 0 || dev >= 16 || !attr_done[dev])) {
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
-    attr_done[dev] = true;
+    if (dev >= 0 && dev < 16) attr_done[dev] = true;
   }
   const uint32_t ngroups = (batch + PL::TPB - 1) / PL::TPB;
   const uint32_t gx = ngroups < 65536u ? ngroups : 65536u, gy = (ngroups + gx - 1) / gx;
+  note_kernel(ARMFFT_KNAME_Q("cfft_fixed_kernel"), false, LOGN);
   kern<<<dim3(gx, gy, 1), PL::T, lds_bytes, stream>>>(data, tw, batch, ngroups, bitrev ? 1 : 0);
   return hipGetLastError();
 }
@@ -1173,6 +1200,7 @@ static hipError_t launch_rfft_fixed_direct(const typename Q::word *in, typename 
   }
   const uint32_t groups = (batch + PL::TPB - 1) / PL::TPB;
   const uint32_t gx = groups < 65536u ? groups : 65536u, gy = (groups + gx - 1) / gx;
+  note_kernel(ARMFFT_KNAME_Q("rfft_fixed_direct_kernel"), false, LOGN);
   kern<<<dim3(gx, gy, 1), PL::WG, lds_bytes, stream>>>(in, out, tw, A, B, mod, batch);
   return hipGetLastError();
 }
@@ -1189,13 +1217,14 @@ static hipError_t launch_rfft_fixed_one(const typename Q::word *in, typename Q::
   int dev = 0;
   (void)hipGetDevice(&dev);
   auto kern = rfft_fixed_kernel<Q, LOGN, INV>;
-  if (lds_bytes > 48 * 1024 && dev < 16 && !attr_done[dev]) {
+  if (lds_bytes > 48 * 1024 && (dev < 0 || dev >= 16 || !attr_done[dev])) {
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
-    attr_done[dev] = true;
+    if (dev >= 0 && dev < 16) attr_done[dev] = true;
   }
   const uint32_t ngroups = (batch + PL::TPB - 1) / PL::TPB;
   const uint32_t gx = ngroups < 65536u ? ngroups : 65536u;
+  note_kernel(ARMFFT_KNAME_Q("rfft_fixed_kernel"), false, LOGN);
   kern<<<dim3(gx, (ngroups + gx - 1) / gx, 1), PL::T, lds_bytes, stream>>>(in, out, tw, A, B, mod, batch, ngroups, bitrev ? 1 : 0);
   return hipGetLastError();
 }

@@ -46,6 +46,7 @@ __constant__ int8_t k_g2_taps[37][2] = {
     {6, 8}, {7, 9}, {0, 5}, {1, 6}, {2, 7}, {3, 8}, {4, 9}, {3, 9}, {0, 6}, {1, 7}, {3, 9}};
 
 constexpr int kCodeLen = 1023;
+constexpr float kRefPiF = 3.14159265358979f;   // the reference's PI: a FLOAT literal (Include/gnss_codes.h:33), 3.1415927410125732 as a double
 
 // one sequence per workgroup at every size: N/16 threads
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -175,19 +176,40 @@ __global__ void gnss_expand_code_kernel(const int8_t *__restrict__ chips, int32_
   if (n < total) out[n] = chips[(n / spc) % kCodeLen];
 }
 
-// probe of synth_gps_prn / mix_prn (gnss_codes.c:1032-1071): replica[n] = code[n] e^{j 2 pi f n / FS}
-__global__ void gnss_replica_kernel(const int8_t *__restrict__ chips, float2 *__restrict__ out, int size, int spc, double doppler,
-                                    double phase_cycles)
+// probe of synth_gps_prn / mix_prn (gnss_codes.c:1032-1071): replica[n] = code[n] e^{j (phi0 + n dth)}.  The reference
+// advances a double phasor by one complex multiplication per sample and renormalises it (:1055-1061); here every sample
+// evaluates its own phase in double -- the recursion's accumulated rounding (< 1e-12 over 16384 samples) is far below the
+// float rounding of the result, so the two agree to the last float bit except on rounding ties.  dth and phi0 come from
+// the host, computed with the reference's own constants (mix_prn uses the FLOAT literal PI of Include/gnss_codes.h:33,
+// make_replica the double M_PI of quasi_pilot_tests.c:10-12).
+__global__ void gnss_replica_kernel(const int8_t *__restrict__ chips, float2 *__restrict__ out, int size, int spc, double dth, double phi0)
 {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= size) return;
-  const double FS = 1.023e6 * spc;
-  double cyc = doppler * (double)n / FS + phase_cycles;
-  cyc -= floor(cyc);
   double s, c;
-  sincospi(2.0 * cyc, &s, &c);
+  sincos(phi0 + (double)n * dth, &s, &c);
   const double a = (double)chips[(n / spc) % kCodeLen];
   out[n] = make_float2((float)(a * c), (float)(a * s));
+}
+
+// mix_prn (gnss_codes.c:1032-1063) / make_replica (quasi_pilot_tests.c:153-181) on a caller-supplied code of `size` ints
+__global__ void gnss_mix_code_kernel(const int32_t *__restrict__ code, float2 *__restrict__ out, int size, double dth, double phi0)
+{
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= size) return;
+  double s, c;
+  sincos(phi0 + (double)n * dth, &s, &c);
+  const double a = (double)code[n];   // :1046 / :164
+  out[n] = make_float2((float)(a * c), (float)(a * s));
+}
+
+// rotate_fwd (quasi_pilot_tests.c:138-151): out[i] = in[i - offset], indices wrapped once
+__global__ void gnss_rotate_kernel(const int32_t *__restrict__ in, int32_t *__restrict__ out, int size, int offset)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= size) return;
+  const int j = i - offset;
+  out[i] = in[j < 0 ? size + j : j];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -902,6 +924,7 @@ hipError_t launch_acquire(const gnss_acq_plan *pl, const void *sig, int packed, 
   static std::atomic<bool> done[16];
   hipError_t e = lds_attr_once(k, lds, done, pl->device);
   if (e != hipSuccess) return e;
+  note_kernel("gnss_acquire_kernel<%d>", false, LOGN);
   k<<<dim3(d1 - d0, n_scenes), PL::T, lds, s>>>(sig, packed, pl->spectra_dev, pl->tw, pl->dops_dev, pl->prns_dev, pl->n_prn, pl->n_dop, d0,
                                                 pl->n_ms, pl->spm, pl->fs_hz, pl->pk_sep, all);
   return hipGetLastError();
@@ -918,16 +941,19 @@ hipError_t launch_groups(const gnss_acq_plan *pl, const void *sig, int packed, u
   static std::atomic<bool> done_a[16], done_b1[16], done_b2[16];
   hipError_t e = lds_attr_once(ka, lds_a, done_a, pl->device);
   if (e != hipSuccess) return e;
+  note_kernel("gnss_group_spectra_kernel<%d>", false, LOGN);
   ka<<<dim3(d1 - d0, n_scenes, n_groups), PL::T, lds_a, s>>>(sig, packed, pl->tw, pl->dops_dev, d0, pl->n_ms, pl->n_ms / n_groups, pl->spm,
                                                              pl->fs_hz, work);
   if ((e = hipGetLastError()) != hipSuccess) return e;
   if (mode == 1) {
     auto kb = gnss_accumulate_kernel<LOGN, 1>;
     if ((e = lds_attr_once(kb, lds_b, done_b1, pl->device)) != hipSuccess) return e;
+    note_kernel("gnss_accumulate_kernel<%d, 1>", true, LOGN);
     kb<<<dim3(d1 - d0, n_scenes), PL::T, lds_b, s>>>(work, pl->spectra_dev, pl->tw, pl->prns_dev, pl->n_prn, pl->n_dop, d0, n_groups, pl->pk_sep, all);
   } else {
     auto kb = gnss_accumulate_kernel<LOGN, 2>;
     if ((e = lds_attr_once(kb, lds_b, done_b2, pl->device)) != hipSuccess) return e;
+    note_kernel("gnss_accumulate_kernel<%d, 2>", true, LOGN);
     kb<<<dim3(d1 - d0, n_scenes), PL::T, lds_b, s>>>(work, pl->spectra_dev, pl->tw, pl->prns_dev, pl->n_prn, pl->n_dop, d0, n_groups, pl->pk_sep, all);
   }
   return hipGetLastError();
@@ -1328,10 +1354,49 @@ arm_status gnss_synth_gps_prn_dev(int32_t prn, float doppler, uint32_t size, flo
   const int8_t *chips = nullptr;
   arm_status st = chips_for(prn, &chips);
   if (st != ARM_MATH_SUCCESS) return st;
+  // mix_prn's own arithmetic (gnss_codes.c:1035-1042): FS = 1.023e6 * spc, dth = 2.0 * PI * f / FS with the FLOAT literal PI
+  const double FS = 1.023e6 * samples_per_chip, dth = 2.0 * (double)kRefPiF * (double)doppler / FS;
   gnss_replica_kernel<<<(size + 255) / 256, 256, 0, nullptr>>>(chips, reinterpret_cast<float2 *>(replica_dev), (int)size, samples_per_chip,
-                                                               (double)doppler, 0.0);
+                                                               dth, 0.0 * (double)kRefPiF / 180.0);
   bool ok = hip_ok(hipGetLastError(), "gnss_replica_kernel") && hip_ok(hipStreamSynchronize(nullptr), "synchronise");
   return ok ? ARM_MATH_SUCCESS : ARM_MATH_ARGUMENT_ERROR;
+}
+
+// mix_prn (gnss_codes.c:1032-1063) on a caller-supplied code: signal[n] = code[n] e^{j (phase + 2 PI f n / FS)}, FS = 1.023e6 spc
+arm_status gnss_mix_prn_dev(const int32_t *code_dev, double doppler_hz, double phase_deg, float *signal_dev, uint32_t size, int32_t spc,
+                            void *stream)
+{
+  if (!code_dev || !signal_dev || spc < 1 || size > 0x7fffffffu) { set_error("gnss_mix_prn_dev: bad argument"); return ARM_MATH_ARGUMENT_ERROR; }
+  if (size == 0) return ARM_MATH_SUCCESS;
+  const double FS = 1.023e6 * spc;                                                   // :1035
+  const double dth = 2.0 * (double)kRefPiF * doppler_hz / FS;                        // :1037, PI = 3.14159265358979f
+  const double phi0 = phase_deg * (double)kRefPiF / 180.0;                           // :1041-1042
+  gnss_mix_code_kernel<<<(size + 255) / 256, 256, 0, (hipStream_t)stream>>>(code_dev, reinterpret_cast<float2 *>(signal_dev), (int)size, dth, phi0);
+  return hip_ok(hipGetLastError(), "gnss_mix_code_kernel") ? ARM_MATH_SUCCESS : ARM_MATH_ARGUMENT_ERROR;
+}
+
+// make_replica (quasi_pilot_tests.c:153-181): carrier at `doppler` on a caller-supplied code, initial phase 0.0001 degrees
+arm_status gnss_make_replica_dev(const int32_t *code_dev, uint32_t size, float doppler, float samp_freq, float *out_dev, void *stream)
+{
+  if (!code_dev || !out_dev || size > 0x7fffffffu) { set_error("gnss_make_replica_dev: bad argument"); return ARM_MATH_ARGUMENT_ERROR; }
+  if (size == 0) return ARM_MATH_SUCCESS;
+  const double dth = 2.0 * M_PI * (double)doppler / (double)samp_freq;               // :157
+  const double phi0 = 0.0001 * (double)M_PI / 180.0f;                                // :155, :160-161
+  gnss_mix_code_kernel<<<(size + 255) / 256, 256, 0, (hipStream_t)stream>>>(code_dev, reinterpret_cast<float2 *>(out_dev), (int)size, dth, phi0);
+  return hip_ok(hipGetLastError(), "gnss_mix_code_kernel") ? ARM_MATH_SUCCESS : ARM_MATH_ARGUMENT_ERROR;
+}
+
+// rotate_fwd (quasi_pilot_tests.c:138-151), out of place on device pointers; 0 <= offset <= size (the reference indexes outside
+// the array for any other offset)
+arm_status gnss_rotate_fwd_dev(const int32_t *in_dev, int32_t *out_dev, uint32_t size, int32_t offset, void *stream)
+{
+  if (!in_dev || !out_dev || in_dev == out_dev || size > 0x7fffffffu || offset < 0 || (uint32_t)offset > size) {
+    set_error("gnss_rotate_fwd_dev: bad argument (0 <= offset <= size, out of place)");
+    return ARM_MATH_ARGUMENT_ERROR;
+  }
+  if (size == 0) return ARM_MATH_SUCCESS;
+  gnss_rotate_kernel<<<(size + 255) / 256, 256, 0, (hipStream_t)stream>>>(in_dev, out_dev, (int)size, offset);
+  return hip_ok(hipGetLastError(), "gnss_rotate_kernel") ? ARM_MATH_SUCCESS : ARM_MATH_ARGUMENT_ERROR;
 }
 
 arm_status gnss_find_top2_peaks_dev(const float *data_dev, int32_t is_complex, int32_t data_size, int32_t pk_sep, uint32_t batch,
@@ -1389,9 +1454,49 @@ void synth_gps_prn(int prn, float doppler, size_t size, float32_t *replica, int 
     die("synth_gps_prn");
 }
 
+// gnss_codes.c:1032-1063 (external linkage there, although Include/gnss_codes.h does not declare it)
+void mix_prn(const int32_t *prn_a, const double doppler_a_hz, const double phase_a_deg, float32_t *signal, int size, int spc)
+{
+  if (!prn_a || !signal || size <= 0) return;
+  DevBuf c((size_t)size * sizeof(int32_t)), d((size_t)size * sizeof(float2));
+  if (!c.p || !d.p || !hip_ok(hipMemcpy(c.p, prn_a, (size_t)size * sizeof(int32_t), hipMemcpyHostToDevice), "hipMemcpy(H2D)") ||
+      gnss_mix_prn_dev((const int32_t *)c.p, doppler_a_hz, phase_a_deg, (float *)d.p, (uint32_t)size, spc, nullptr) != ARM_MATH_SUCCESS ||
+      !hip_ok(hipMemcpy(signal, d.p, (size_t)size * sizeof(float2), hipMemcpyDeviceToHost), "hipMemcpy(D2H)"))
+    die("mix_prn");
+}
+
+// quasi_pilot_tests.c:153-181 (Include/gnss_codes.h:110)
+void make_replica(const int32_t *prn_a, float32_t *out_iandq, float doppler, int size, float samp_freq)
+{
+  if (!prn_a || !out_iandq || size <= 0) return;
+  DevBuf c((size_t)size * sizeof(int32_t)), d((size_t)size * sizeof(float2));
+  if (!c.p || !d.p || !hip_ok(hipMemcpy(c.p, prn_a, (size_t)size * sizeof(int32_t), hipMemcpyHostToDevice), "hipMemcpy(H2D)") ||
+      gnss_make_replica_dev((const int32_t *)c.p, (uint32_t)size, doppler, samp_freq, (float *)d.p, nullptr) != ARM_MATH_SUCCESS ||
+      !hip_ok(hipMemcpy(out_iandq, d.p, (size_t)size * sizeof(float2), hipMemcpyDeviceToHost), "hipMemcpy(D2H)"))
+    die("make_replica");
+}
+
+// quasi_pilot_tests.c:138-151 (Include/gnss_codes.h:111), in place on the caller's array like the reference
+void rotate_fwd(int array[], int size, int offset)
+{
+  if (!array || size <= 0) return;
+  if (offset < 0 || offset > size) {   // the reference reads outside the array here; refuse and leave the array as it is
+    set_error("rotate_fwd: offset %d outside 0..%d, array left unchanged", offset, size);
+    return;
+  }
+  DevBuf a((size_t)size * sizeof(int32_t)), b((size_t)size * sizeof(int32_t));
+  if (!a.p || !b.p || !hip_ok(hipMemcpy(a.p, array, (size_t)size * sizeof(int32_t), hipMemcpyHostToDevice), "hipMemcpy(H2D)") ||
+      gnss_rotate_fwd_dev((const int32_t *)a.p, (int32_t *)b.p, (uint32_t)size, offset, nullptr) != ARM_MATH_SUCCESS ||
+      !hip_ok(hipMemcpy(array, b.p, (size_t)size * sizeof(int32_t), hipMemcpyDeviceToHost), "hipMemcpy(D2H)"))
+    die("rotate_fwd");
+}
+
 static int top2_host(const float *data, int is_complex, int data_size, int pk_sep, top2_pks *peaks, FILE *fp_out)
 {
   if (data_size <= 0 || !data || !peaks) return -1;  // :1145 / :1169
+  // a negative pk_sep makes "abs(m - idx1) > pk_sep" true for every pair of distinct indices, exactly as pk_sep = 0 does
+  // (m never equals idx1 when the test runs): the reference accepts it, and so does this wrapper
+  if (pk_sep < 0) pk_sep = 0;
   if (fp_out) {  // the reference's debug dump of every magnitude (:1151, :1175): formatting only
     for (int m = 0; m < data_size; m++) {
       const float magn = is_complex ? sqrtf(data[2 * m] * data[2 * m] + data[2 * m + 1] * data[2 * m + 1]) : data[m];
@@ -1417,7 +1522,13 @@ int find_top2_peaks_real(const float32_t *data, int data_size, int pk_sep, top2_
 
 static double snr_host(const float *convol, int is_complex, int cov_size, double peak, int peak_loc, const char *who)
 {
-  if (!convol || cov_size <= 0) { set_error("%s: bad argument", who); die(who); }
+  if (cov_size <= 0) {
+    // the reference's loop does not run and reads nothing (:1112 / :1129); what is left is scalar arithmetic on the
+    // arguments: mean = 0 / (cov_size - 5), 10 log10(peak / mean) -- an infinity or a NaN, returned like the reference does
+    const double mean = 0.0 / (double)(cov_size - 5);
+    return 10.0 * log10(peak / mean);
+  }
+  if (!convol) { set_error("%s: null data", who); die(who); }
   const size_t bytes = (size_t)cov_size * (is_complex ? 2 : 1) * sizeof(float);
   DevBuf d(bytes), r(sizeof(double));
   double snr = 0.0;

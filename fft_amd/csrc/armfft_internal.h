@@ -15,6 +15,11 @@ constexpr int kMinLargeLog = 15, kMaxLargeLog = 22;  // four-step through HBM
 void set_error(const char *fmt, ...);
 bool hip_ok(hipError_t e, const char *what);
 
+// Name of the kernel the calling thread launched last, for arm_fft_mi355_last_kernel (bench.py puts it next to
+// its roofline numbers so that the line can be matched to a rocprof trace).  fmt is a string LITERAL with up to five
+// %d; nothing is formatted until somebody asks.  append: a second kernel of the same call (the four-step's pass 2).
+void note_kernel(const char *fmt, bool append, int a = 0, int b = 0, int c = 0, int d = 0, int e = 0);
+
 // per-device cached table exp(-2 pi i m / 2^logn), m < 2^logn (armfft_abi.cpp); nullptr + error on failure
 const float2 *dev_twiddle_f32(int logn);
 // three-level table of W_N for the four-step kernels (armfft_large.hip), same caching

@@ -240,6 +240,9 @@ static hipError_t launch_pass(const float2 *in, float2 *out, const float2 *tw, c
   if (n_items > 0x7fffffffull) return hipErrorInvalidValue;
   // pair mapping (64-byte runs only): whole pairs, and a grid that is a multiple of 16 (two slots on each of the 8 XCDs)
   const int paired = (MODE == 1 && PL::TPB == 8 && tiles % 2 == 0 && n_items % 16 == 0) ? 1 : 0;
+  note_kernel(INV ? (TILED ? "fourstep_tile_kernel<%d, %d, true, true, %d, %d>" : "fourstep_tile_kernel<%d, %d, true, false, %d, %d>")
+                  : (TILED ? "fourstep_tile_kernel<%d, %d, false, true, %d, %d>" : "fourstep_tile_kernel<%d, %d, false, false, %d, %d>"),
+              MODE == 2, LOGA, MODE, E, POL);
   kern<<<(uint32_t)n_items, 1024, lds_bytes, stream>>>(in, out, tw, tw_big, log_other, tiles, (uint32_t)n_items, paired, log_blk, scale);
   return hipGetLastError();
 }
@@ -349,6 +352,10 @@ static __device__ __align__(256) unsigned char armfft_noalloc_scratch[kNoAllocSc
 
 namespace {
 std::atomic<float2 *> g_scratch_ptr[16];   // per device, resolved once with that device current
+// per (device, log2 fftLen): arm_cfft_u32_f32_noalloc_prepare ran to the end -- tables built, scratch address resolved, every
+// kernel of that size launched once (so its attributes are set).  Tables that arm_cfft_u32_f32_dev happened to create for
+// the same sub-sizes are NOT proof of that: the allocation-free call asks this flag, nothing else.
+std::atomic<bool> g_noalloc_prepared[16][armfft::kMaxLargeLog + 1];
 
 float2 *noalloc_scratch(int dev)
 {
@@ -388,6 +395,7 @@ arm_status arm_cfft_u32_f32_noalloc_prepare(uint32_t fftLen)
             hip_ok(launch_cfft_large_f32(l, scr, work, tw1, tw2, big, 1, false, nullptr), "four-step warm-up (forward)") &&
             hip_ok(launch_cfft_large_f32(l, scr, work, tw1, tw2, big, 1, true, nullptr), "four-step warm-up (inverse)") &&
             hip_ok(hipStreamSynchronize(nullptr), "synchronise");
+  if (ok) g_noalloc_prepared[dev][l].store(true, std::memory_order_release);
   return ok ? ARM_MATH_SUCCESS : ARM_MATH_ARGUMENT_ERROR;
 }
 
@@ -414,11 +422,12 @@ arm_status arm_cfft_u32_f32_noalloc_dev(const arm_cfft_instance_u32_f32 *S, floa
   if (batch == 0) return ARM_MATH_SUCCESS;
   int dev = 0;
   if (!hip_ok(hipGetDevice(&dev), "hipGetDevice")) return ARM_MATH_ARGUMENT_ERROR;
-  float2 *scr = noalloc_scratch(dev);
-  if (!scr) return ARM_MATH_ARGUMENT_ERROR;
+  // everything below only READS what prepare left behind: no hipGetSymbolAddress, no hipFuncSetAttribute on this path
+  const bool prepared = dev >= 0 && dev < 16 && g_noalloc_prepared[dev][l].load(std::memory_order_acquire);
+  float2 *scr = prepared ? g_scratch_ptr[dev].load(std::memory_order_acquire) : nullptr;
   const int l2 = l / 2, l1 = l - l2;
   const float2 *tw1 = dev_twiddle_f32_peek(l1), *tw2 = dev_twiddle_f32_peek(l2), *big = dev_twiddle_lo_peek(l);
-  if (!tw1 || !tw2 || !big) {
+  if (!prepared || !scr || !tw1 || !tw2 || !big) {
     set_error("%s: no plan for fftLen %u on device %d: call arm_cfft_u32_f32_noalloc_prepare(%u) once first (this entry point never allocates)", who, n, dev, n);
     return ARM_MATH_ARGUMENT_ERROR;
   }

@@ -374,6 +374,22 @@ arm_status gnss_get_code_dev(int32_t num, int32_t samples_per_chip, int32_t prn,
 arm_status gnss_synth_gps_prn_dev(int32_t prn, float32_t doppler, uint32_t size, float32_t *replica_dev, int32_t samples_per_chip);
 arm_status gnss_find_top2_peaks_dev(const float32_t *data_dev, int32_t is_complex, int32_t data_size, int32_t pk_sep, uint32_t batch,
                                     gnss_top2 *peaks_dev, void *stream);
+/* Carrier mixing on a CALLER-SUPPLIED code of `size` ints (one per sample, normally +1 / -1), device pointers,
+ * asynchronous on `stream`, no allocation:
+ *   gnss_mix_prn_dev       mix_prn (gnss_codes.c:1032-1063): signal[n] = code[n] e^{j (phase + 2 PI f n / FS)}, FS = 1.023e6 * spc,
+ *                          with the reference's FLOAT literal PI (Include/gnss_codes.h:33) in both places;
+ *   gnss_make_replica_dev  make_replica (quasi_pilot_tests.c:153-181, Include/gnss_codes.h:110): the same on a caller-given
+ *                          sample rate, initial phase 0.0001 degrees, double M_PI;
+ *   gnss_rotate_fwd_dev    rotate_fwd (quasi_pilot_tests.c:138-151): out[i] = in[i - offset] (wrapped), out of place,
+ *                          0 <= offset <= size.
+ * Every sample's phase is evaluated directly in double instead of by the reference's renormalised recursive phasor:
+ * results agree with the reference to one float ulp (tests/golden/gnss_replica.npz holds make_replica outputs of the
+ * reference's own code compiled here). */
+arm_status gnss_mix_prn_dev(const int32_t *code_dev, double doppler_hz, double phase_deg, float32_t *signal_dev, uint32_t size, int32_t spc,
+                            void *stream);
+arm_status gnss_make_replica_dev(const int32_t *code_dev, uint32_t size, float32_t doppler, float32_t samp_freq, float32_t *out_dev,
+                                 void *stream);
+arm_status gnss_rotate_fwd_dev(const int32_t *in_dev, int32_t *out_dev, uint32_t size, int32_t offset, void *stream);
 
 /* The reference's own names for those helpers (Include/gnss_codes.h:62-126), host pointers; `c32` arrays are passed
  * as interleaved float32_t I/Q (Include/cplx_types.h:9: struct { float r, i; }, same memory).  Each stages its
@@ -381,10 +397,17 @@ arm_status gnss_find_top2_peaks_dev(const float32_t *data_dev, int32_t is_comple
  *   getCode                 gnss_codes.c:969-1030   out[num * samplesPerChip] ints, +1 / -1
  *   synth_gps_prn           :1066-1071 (mix_prn :1032-1063)   replica[size] c32; carrier by direct evaluation of the
  *                           double phase instead of the reference's renormalised recursive phasor (<= 1.2e-7 apart)
+ *   mix_prn                 :1032-1063 (external linkage in gnss_codes.c, not declared in gnss_codes.h)
+ *   make_replica, rotate_fwd   quasi_pilot_tests.c:153-181, :138-151 (Include/gnss_codes.h:110-111); rotate_fwd leaves the array
+ *                           unchanged (message in arm_fft_mi355_last_error) for an offset outside 0..size, where the
+ *                           reference reads outside the array
  *   find_top2_peaks_cplx / _real   :1144-1190   same values and indices as the sequential loop, ties included;
- *                           data_size <= 16384; fp_out (optional) receives the reference's "m, magnitude" dump;
+ *                           data_size <= 16384 (the fork's largest correlation; -1 beyond it -- the reference has no limit);
+ *                           a negative pk_sep behaves as 0, which is what the reference's comparison makes of it;
+ *                           fp_out (optional) receives the reference's "m, magnitude" dump;
  *                           returns -1 on a bad argument or when the GPU cannot run (0 = success)
- *   compute_snr_cplx / _real       :1110-1142   10 log10(peak / mean off-peak magnitude)
+ *   compute_snr_cplx / _real       :1110-1142   10 log10(peak / mean off-peak magnitude); cov_size <= 0 returns what the
+ *                           reference's arithmetic gives without reading data (an infinity or a NaN), it does not abort
  *   InterpolateCodePhase    :1096-1108   scalar formula on three doubles (host arithmetic: no data to move)
  * The void / double entry points abort() with a message when the GPU cannot run them (see Conventions). */
 typedef struct {          /* Include/gnss_codes.h:42-47 */
@@ -395,6 +418,9 @@ typedef struct {          /* Include/gnss_codes.h:42-47 */
 } top2_pks;
 void getCode(int num, int samplesPerChip, const int prn, int *out);
 void synth_gps_prn(int prn, float doppler, size_t size, float32_t *replica, int spc);
+void mix_prn(const int32_t *prn_a, const double doppler_a_hz, const double phase_a_deg, float32_t *signal, int size, int spc);
+void make_replica(const int32_t *prn_a, float32_t *out_iandq, float doppler, int size, float samp_freq);
+void rotate_fwd(int array[], int size, int offset);
 int find_top2_peaks_cplx(const float32_t *data, int data_size, int pk_sep, top2_pks *peaks, FILE *fp_out);
 int find_top2_peaks_real(const float32_t *data, int data_size, int pk_sep, top2_pks *peaks, FILE *fp_out);
 double compute_snr_cplx(float32_t *convol, int cov_size, double peak, int peak_loc);
@@ -522,8 +548,19 @@ arm_status arm_fft_mi355_set_device(int device);
 arm_status arm_fft_mi355_warm(int kind, uint32_t fftLen);
 /* Message of the last failure on the calling thread ("" if none). */
 const char *arm_fft_mi355_last_error(void);
-/* Rounding rule of the fixed-point twiddle tables: 0 = floor (default), 1 = nearest.  Must be
- * set before the first q15/q31 init; see DESIGN.md "fixed-point twiddles". */
+/* Name(s) of the kernel(s) the calling thread's last transform or acquisition call launched, spelled as rocprofv3
+ * prints them without the namespace and argument list, e.g. "cfft_f32_split_kernel<12, false, 0>" or
+ * "fourstep_tile_kernel<11, 1, false, true, 32, 0> + fourstep_tile_kernel<11, 2, false, true, 16, 0>" ("" before the
+ * first launch).  bench.py prints it next to its roofline figures so that a line can be matched to a trace. */
+const char *arm_fft_mi355_last_kernel(void);
+/* Rule the fixed-point twiddle tables (Include/arm_common_tables.h:88-130; definitions missing from the reference's
+ * mount) are generated by.  Must be set before the first q15/q31 init; see DESIGN.md section 4.
+ *   0  floor(x * 2^15 | 2^31) of the double value, +1.0 saturated (upstream's scalar tables, as recollected)
+ *   1  round to nearest, the same otherwise (the two copies the mount holds: arm_mve_tables.c:3769, arm_neon_tables.c:8951)
+ *   2  the fork's own generator, twiddleCoefCalculator + to_fixed (CMSIS/CMSIS.cpp:445-458, :309-327): FLOAT angle
+ *      i*2*PI/(float)N, float cos / sin, float product with 2^dyad, llround, negatives one lower, clamps
+ *   3  (default) per size: rule 0 up to 4096 points, rule 2 at 8192 / 16384 -- the sizes the fork added with that generator
+ * Returns ARM_MATH_ARGUMENT_ERROR for another value or once a fixed-point table exists. */
 arm_status arm_fft_mi355_set_twiddle_rounding(int mode);
 const char *arm_fft_mi355_version(void);
 

@@ -23,7 +23,10 @@
  *   rfft  : tw[2i] = (float)sin(2 pi i/N), tw[2i+1] = (float)cos(2 pi i/N), i < N/2
  *           (TW = i*exp(-2 pi i k/L), arm_rfft_fast_f32.c:362-373)
  *   q15/31: 3N/4 (cos, sin) pairs scaled by 2^15 / 2^31, +1.0 saturated to 0x7FFF / 0x7FFFFFFF.
- *           rounding = floor (default) or nearest -- the one documented switch.
+ *           rounding = ORC_TW_FLOOR, ORC_TW_ROUND (both on the double value, exact at multiples of
+ *           pi/2) or ORC_TW_FORK: the fork's own generator twiddleCoefCalculator + to_fixed
+ *           (CMSIS/CMSIS.cpp:445-458, :309-327), the only table rule the mount holds in source
+ *           and the one the fork's 8192/16384 tables were printed with (fork_twiddle below).
  * ------------------------------------------------------------------------------------------ */
 void orc_twiddle_f32(uint32_t N, float *tw)
 {
@@ -67,8 +70,54 @@ static void exact_cs(uint32_t i, uint32_t N, double *c, double *s)
   }
 }
 
+/* The fork's generator, restated operation by operation.
+ *   twiddleCoefCalculator (CMSIS/CMSIS.cpp:452-456):
+ *       float c = cos(i * 2 * PI / (float)fft_len), s = sin(same)
+ *     PI is the FLOAT literal 3.14159265358979f (Include/gnss_codes.h:33, dsp/fast_math_functions.h:54),
+ *     so i*2 is an int, (i*2)*PI a float product and the division a float division: the angle
+ *     carries a relative error of up to ~9e-8 (PI's own float rounding included) before cos/sin
+ *     ever see it.  cos/sin of that float, result stored to float (taken here as the correctly
+ *     rounded float of the double function; an MSVC cosf that is not correctly rounded could
+ *     differ in the last float bit -- nothing in the mount can settle that).
+ *   to_fixed(f, e) (:309-327): tmp = (float)pow(2.0f, e); b = llround(f * tmp) -- a FLOAT product,
+ *     so a q31 entry has 24 significant bits; clamp "b > 0 && b > max -> max", "b < 0 && b <= min
+ *     -> min" (the constants 2147483647 / -2147483648 carry the comments "32767" / "-32768": the
+ *     author swaps them with the dyad, and so does this restatement); then for b < 0:
+ *     b = abs(b); b = ~b, i.e. -|b| - 1: every negative entry is ONE LOWER than the rounded value.
+ *   No exact values at multiples of pi/2: cos(float(pi/2)) * 2^31 = -93.9 -> -94 -> -95. */
+static int32_t fork_to_fixed(float f, int e, int64_t lo, int64_t hi)
+{
+  float tmp = (float)pow(2.0f, e);
+  int64_t b = (int64_t)llround((double)(f * tmp));   /* llround(float): the float product, then round half away */
+  if (b > 0 && b > hi) return (int32_t)hi;
+  if (b < 0 && b <= lo) return (int32_t)lo;
+  if (b < 0) {
+    b = llabs(b);
+    b = ~b;
+  }
+  return (int32_t)b;
+}
+
+static void fork_cs(uint32_t i, uint32_t N, float *c, float *s)
+{
+  const float PIf = 3.14159265358979f;
+  volatile float num = (float)(int)(i * 2) * PIf;   /* volatile: no contraction / excess precision across the two float steps */
+  volatile float arg = num / (float)N;
+  *c = (float)cos((double)arg);
+  *s = (float)sin((double)arg);
+}
+
 void orc_twiddle_q15(uint32_t N, int16_t *tw, int rounding)
 {
+  if (rounding == ORC_TW_FORK) {
+    for (uint32_t i = 0; i < 3 * N / 4; i++) {
+      float c, s;
+      fork_cs(i, N, &c, &s);
+      tw[2 * i] = (int16_t)fork_to_fixed(c, 15, -32768, 32767);
+      tw[2 * i + 1] = (int16_t)fork_to_fixed(s, 15, -32768, 32767);
+    }
+    return;
+  }
   for (uint32_t i = 0; i < 3 * N / 4; i++) {
     double c, s;
     exact_cs(i, N, &c, &s);
@@ -79,6 +128,15 @@ void orc_twiddle_q15(uint32_t N, int16_t *tw, int rounding)
 
 void orc_twiddle_q31(uint32_t N, int32_t *tw, int rounding)
 {
+  if (rounding == ORC_TW_FORK) {
+    for (uint32_t i = 0; i < 3 * N / 4; i++) {
+      float c, s;
+      fork_cs(i, N, &c, &s);
+      tw[2 * i] = fork_to_fixed(c, 31, INT32_MIN, INT32_MAX);
+      tw[2 * i + 1] = fork_to_fixed(s, 31, INT32_MIN, INT32_MAX);
+    }
+    return;
+  }
   for (uint32_t i = 0; i < 3 * N / 4; i++) {
     double c, s;
     exact_cs(i, N, &c, &s);
@@ -100,8 +158,8 @@ static int is_pow2(uint32_t n) { return n && !(n & (n - 1)); }
 #define ORC_MAXLOG 15
 static float *g_tw_f32[ORC_MAXLOG + 1];
 static float *g_tw_rfft[ORC_MAXLOG + 1];
-static int16_t *g_tw_q15[2][ORC_MAXLOG + 1];
-static int32_t *g_tw_q31[2][ORC_MAXLOG + 1];
+static int16_t *g_tw_q15[3][ORC_MAXLOG + 1];
+static int32_t *g_tw_q31[3][ORC_MAXLOG + 1];
 static uint32_t *g_perm_f32[ORC_MAXLOG + 1];
 
 static const float *tw_f32(uint32_t N)
@@ -127,7 +185,7 @@ static const float *tw_rfft(uint32_t N)
 static const int16_t *tw_q15(uint32_t N, int rounding)
 {
   uint32_t l = ilog2(N);
-  rounding = rounding ? 1 : 0;
+  rounding = (rounding < 0 || rounding > 2) ? 0 : rounding;
   if (!g_tw_q15[rounding][l]) {
     int16_t *t = (int16_t *)malloc(sizeof(int16_t) * 3 * N / 2);
     orc_twiddle_q15(N, t, rounding);
@@ -138,7 +196,7 @@ static const int16_t *tw_q15(uint32_t N, int rounding)
 static const int32_t *tw_q31(uint32_t N, int rounding)
 {
   uint32_t l = ilog2(N);
-  rounding = rounding ? 1 : 0;
+  rounding = (rounding < 0 || rounding > 2) ? 0 : rounding;
   if (!g_tw_q31[rounding][l]) {
     int32_t *t = (int32_t *)malloc(sizeof(int32_t) * 3 * N / 2);
     orc_twiddle_q31(N, t, rounding);

@@ -47,10 +47,13 @@ void orc_get_code(int num, int spc, int prn, int *out)
  * renormalised every sample, FS = 1.023e6 * spc. */
 void orc_mix_prn(const int32_t *code, double doppler_hz, double phase_deg, orc_c32 *sig, int size, int spc)
 {
+  /* PI in gnss_codes.c is the FLOAT literal 3.14159265358979f of Include/gnss_codes.h:33 (promoted to double
+   * 3.1415927410125732 in the expressions below), not M_PI: the replica's frequency is 2.8e-8 high */
+  const double REF_PI = (double)3.14159265358979f;
   double FS = 1.023e6 * spc;
-  double dth = 2.0 * ORC_PI * doppler_hz / FS;
+  double dth = 2.0 * REF_PI * doppler_hz / FS;                                   /* :1037 */
   double ci = cos(dth), si = sin(dth);
-  double pc = cos(phase_deg * ORC_PI / 180.0), ps = sin(phase_deg * ORC_PI / 180.0);
+  double pc = cos(phase_deg * REF_PI / 180.0), ps = sin(phase_deg * REF_PI / 180.0);   /* :1041-1042 */
   for (int n = 0; n < size; n++) {
     double a = (double)code[n];
     sig[n].r = (float)(a * pc);
@@ -62,6 +65,41 @@ void orc_mix_prn(const int32_t *code, double doppler_hz, double phase_deg, orc_c
     pc *= na;
     ps *= na;
   }
+}
+
+/* make_replica (quasi_pilot_tests.c:153-181): the same mixer on a caller-given sample rate, initial phase 0.0001
+ * degrees, and -- unlike mix_prn -- the DOUBLE M_PI (quasi_pilot_tests.c:10-12); `quant` is a constant false there,
+ * so quantize_pm13 / noise never run.  Pinned bit for bit by the reference's own object (oracle/_ref/libquasi_ref.so,
+ * tests/test_oracle_gnss.py) and through tests/golden/gnss_replica.npz. */
+void orc_make_replica(const int32_t *code, orc_c32 *out, float doppler, int size, float samp_freq)
+{
+  const double phase_deg = 0.0001;
+  const double dth = 2.0 * ORC_PI * (double)doppler / (double)samp_freq;        /* :157 */
+  const double ci = cos(dth), si = sin(dth);
+  double pc = cos(phase_deg * (double)ORC_PI / 180.0f), ps = sin(phase_deg * (double)ORC_PI / 180.0f);   /* :160-161 */
+  for (int n = 0; n < size; n++) {
+    double a = (double)code[n];
+    out[n].r = (float)(a * pc);
+    out[n].i = (float)(a * ps);
+    double npc = pc * ci - ps * si, nps = pc * si + ps * ci;
+    pc = npc;
+    ps = nps;
+    double na = 1.0 / sqrt(pc * pc + ps * ps);
+    pc *= na;
+    ps *= na;
+  }
+}
+
+/* rotate_fwd (quasi_pilot_tests.c:138-151); 0 <= offset <= size (anything else indexes outside the array there) */
+int orc_rotate_fwd(int *array, int size, int offset)
+{
+  if (size <= 0 || offset < 0 || offset > size) return -1;
+  int *tmp = (int *)malloc(sizeof(int) * (size_t)size);
+  if (!tmp) return -1;
+  for (int i = 0; i < size; i++) tmp[i] = (i - offset < 0) ? array[size + (i - offset)] : array[i - offset];
+  memcpy(array, tmp, sizeof(int) * (size_t)size);
+  free(tmp);
+  return 0;
 }
 
 /* synth_gps_prn (gnss_codes.c:1066-1071) */

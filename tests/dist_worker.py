@@ -40,5 +40,39 @@ def run(rank, world, port, out_dir):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         np.save(os.path.join(out_dir, "slice_%d.npy" % rank), np.array([b0, b1, t[0].item(), t[1].item()]))
         dist.barrier()
+        # --- bench.py's own step loop with a collective inside the step and a wall-clock preheat:
+        # the preheat makes a different number of passes on every rank, so it must run the collective-free local step;
+        # the W + K step() calls -- one all-gather each -- must pair up across the ranks
+        import time
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        calls = {"step": 0, "local": 0}
+        w = bench.Workload()
+        w.rescale, w.chunk = None, 1 << 30
+
+        def fake_acquire(a, b):
+            time.sleep(0.001 * (1 + rank))                 # ranks of different speed
+            t = D.empty_best(len(prns), prns)
+            t[:, 0] = torch.tensor(float(10 + rank)).view(torch.int32)
+            t[:, 4] = a
+            return t
+
+        def step():
+            calls["step"] += 1
+            w.merged, _ = D.sharded_acquire(fake_acquire, len(H.DOPPLER_GRID), len(prns), row_prns=prns)
+            return 0
+
+        def local_step():
+            calls["local"] += 1
+            time.sleep(0.001 * (1 + 2 * rank))
+            return 0
+
+        w.step, w.local_step = step, local_step
+        ctx = bench.Ctx(rank, world, True, "cpu")
+        t = bench.timed_region(w, 3, 2, 25.0 * (1 + rank), ctx)
+        top = w.merged[:, 0].view(torch.float32)
+        np.save(os.path.join(out_dir, "loop_%d.npy" % rank),
+                np.array([calls["step"], calls["local"], t["n_pre"], float(top.min()), float(top.max()), t["elapsed"], t["elapsed_min"]]))
+        dist.barrier()
     finally:
         dist.destroy_process_group()

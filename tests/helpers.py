@@ -54,6 +54,9 @@ def oracle():
         L.orc_mix_prn.argtypes = [c_i32, ctypes.c_double, ctypes.c_double, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
         L.orc_synth_gps_prn.argtypes = [ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
         L.orc_compute_snr_cplx.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_int]
+        L.orc_make_replica.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_int, ctypes.c_float]
+        L.orc_make_replica.restype = None
+        L.orc_rotate_fwd.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
         L.orc_acquire_cell_reference.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int,
                                                  ctypes.POINTER(OrcTop2), ctypes.c_void_p]
         _oracle = L
@@ -75,6 +78,28 @@ def ref():
     return _ref
 
 
+_quasi = None
+
+
+def ref_quasi():
+    """The reference's quasi_pilot_tests.c compiled here, UNMODIFIED (oracle/_ref/libquasi_ref.so: exports
+    make_replica and rotate_fwd only), or None when it was not built.  RTLD_LAZY: nothing else of that file is bound."""
+    global _quasi
+    if _quasi is None:
+        so = os.path.join(ORACLE_DIR, "_ref", "libquasi_ref.so")
+        if not os.path.exists(so):
+            if os.path.isdir("/root/reference"):
+                subprocess.run(["make", "-C", ORACLE_DIR, "ref"], check=True, capture_output=True)
+            else:
+                return None
+        L = ctypes.CDLL(so, mode=os.RTLD_LAZY)
+        L.make_replica.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_int, ctypes.c_float]
+        L.make_replica.restype = None
+        L.rotate_fwd.argtypes, L.rotate_fwd.restype = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int], None
+        _quasi = L
+    return _quasi
+
+
 _golden = {}
 
 
@@ -82,6 +107,20 @@ def golden(kind):
     if kind not in _golden:
         _golden[kind] = np.load(os.path.join(GOLDEN_DIR, "transform_%s.npz" % kind), allow_pickle=False)
     return _golden[kind]
+
+
+def golden_replicas():
+    """tests/golden/gnss_replica.npz: make_replica / rotate_fwd outputs of the reference's own compiled code
+    (tests/golden/make_gnss_replica.py)."""
+    if "gnss_replica" not in _golden:
+        _golden["gnss_replica"] = np.load(os.path.join(GOLDEN_DIR, "gnss_replica.npz"), allow_pickle=False)
+    return _golden["gnss_replica"]
+
+
+def default_tw_rule(n):
+    """The fixed-point twiddle rule libarmfft_mi355 uses for an n-point complex transform when nothing was selected
+    (arm_fft_mi355_set_twiddle_rounding mode 3): 0 = floor up to 4096 points, 2 = the fork's generator at 8192 / 16384."""
+    return 2 if n >= 8192 else 0
 
 
 CFFT_SIZES = [16, 32, 64, 128, 256, 512, 1024, 2048, 4096]

@@ -19,7 +19,7 @@ def test_header_and_library_agree():
     hdr = open(os.path.join(H.ROOT, "include", "arm_fft_mi355.h")).read()
     declared = set(re.findall(r"\b((?:arm_(?:cfft|rfft_fast|rfft|fft_mi355)|gnss|up_sample|iq_resamp|write_bb|read_bb)_[A-Za-z0-9_]+)\s*\(", hdr))
     # the reference's own GNSS helper names (Include/gnss_codes.h:62-126) carry no common prefix
-    declared |= set(re.findall(r"\b(getCode|synth_gps_prn|find_top2_peaks_cplx|find_top2_peaks_real|compute_snr_cplx|compute_snr_real|InterpolateCodePhase)\s*\(", hdr))
+    declared |= set(re.findall(r"\b(getCode|synth_gps_prn|mix_prn|make_replica|rotate_fwd|find_top2_peaks_cplx|find_top2_peaks_real|compute_snr_cplx|compute_snr_real|InterpolateCodePhase)\s*\(", hdr))
     assert declared, "no declarations found"
     missing = [s for s in sorted(declared) if not hasattr(lib, s)]
     assert not missing, "declared but not exported: %s" % missing
@@ -73,9 +73,11 @@ def test_cfft_init_fixed(n, kind):
     dt, ct = (np.int16, H.c_i16) if kind == "q15" else (np.int32, H.c_i32)
     tw = np.ctypeslib.as_array(S.pTwiddle, shape=(3 * n // 2,))
     want = np.zeros(3 * n // 2, dt)
-    getattr(H.oracle(), "orc_twiddle_" + kind)(n, H.ptr(want, ct), 0)
+    # the library's default rule is per size: floor up to 4096 points, the fork's own generator
+    # (CMSIS/CMSIS.cpp:445-458) at the sizes the fork added
+    getattr(H.oracle(), "orc_twiddle_" + kind)(n, H.ptr(want, ct), H.default_tw_rule(n))
     assert np.array_equal(tw, want)
-    # spot values of the documented rule: +1.0 saturates, floor rounding
+    # spot values: +1.0 saturates under every rule; floor keeps sin(0) = 0
     assert tw[0] == (32767 if kind == "q15" else 2 ** 31 - 1) and tw[1] == 0
 
 

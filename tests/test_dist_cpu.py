@@ -62,3 +62,26 @@ def test_doppler_sharded_acquisition_merges_to_the_single_process_answer(world, 
         ends.append((b0, b1))
         assert mx == -(-1000 // world) and tmax == float(world)
     assert ends[0][0] == 0 and ends[-1][1] == 1000
+    # bench.py's step loop over gloo: W + K = 5 collective steps on every rank, preheat passes (collective-free) as many
+    # as each rank's own clock allowed, the merged winner = the highest rank's peak everywhere, one elapsed for all
+    loops = [np.load(os.path.join(tmp_path, "loop_%d.npy" % r)) for r in range(world)]
+    for r, (n_step, n_local, n_pre, lo, hi, el, el_min) in enumerate(loops):
+        assert n_step == 5 and n_local == n_pre and n_pre >= 4 and n_pre % 4 == 0, (r, n_step, n_local, n_pre)
+        assert lo == hi == float(10 + world - 1)
+        assert el == loops[0][5] and el_min <= el
+    assert len({int(x[1]) for x in loops}) >= 1
+
+
+def test_bench_refuses_more_gpus_than_the_node_has_and_a_world_size_mismatch():
+    """`bench.py --gpus N` is a real request: without N GPUs it exits non-zero with a message instead of
+    printing a one-GPU line; under torch.distributed.run a WORLD_SIZE that differs from --gpus is refused as well."""
+    import subprocess
+    bench = os.path.join(H.ROOT, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "--gpus 2" in r.stderr and "GPU(s) visible" in r.stderr and not r.stdout.strip()
+    r = subprocess.run([sys.executable, bench, "--gpus", "4", "--steps", "1"], env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr and not r.stdout.strip()
+    r = subprocess.run([sys.executable, bench, "--gpus", "0"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0

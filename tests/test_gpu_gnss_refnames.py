@@ -237,3 +237,100 @@ def test_gnss_acquire_multi_equals_single_plan_search(n_plans):
         lib.gnss_acq_plan_destroy(other)
     for p in plans:
         lib.gnss_acq_plan_destroy(p)
+
+
+# ---------------------------------------------------------------- make_replica / mix_prn / rotate_fwd
+@pytest.mark.gpu
+def test_make_replica_vs_reference_fixtures():
+    """make_replica (quasi_pilot_tests.c:153-181) on the GPU against tests/golden/gnss_replica.npz = the outputs of the
+    reference's OWN object code (the file compiles unmodified, oracle/Makefile: libquasi_ref.so): the first
+    reference-executed GNSS vectors in the tree.  Bar: 1.2e-7 (one float ulp at |x| <= 1), as for synth_gps_prn; the
+    device evaluates each sample's phase directly, the reference by a renormalised double recursion."""
+    import torch
+    import gpu_util as G
+    fa, lib = _lib()
+    g = H.golden_replicas()
+    seen = 0
+    for k, row in enumerate(g["cases"]):
+        code = g["code_%d" % k].astype(np.int32)
+        want = g["replica_%d" % k]
+        size, dop, fs = int(row["size"]), float(row["doppler"]), float(row["samp_freq"])
+        # host pointers, the reference's name
+        got = np.full((size, 2), np.nan, np.float32)
+        lib.make_replica(code.ctypes.data_as(vp), got.ctypes.data_as(vp), dop, size, fs)
+        assert np.abs(got - want).max() <= 1.2e-7, (k, np.abs(got - want).max())
+        assert (got == want).mean() > 0.999, (k, (got != want).sum())
+        # device pointers
+        cd = torch.from_numpy(code).cuda()
+        out = torch.full((size, 2), float("nan"), device="cuda")
+        G.check(lib.gnss_make_replica_dev(vp(cd.data_ptr()), size, dop, fs, vp(out.data_ptr()), G.stream_ptr()))
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), got)
+        seen += 1
+    assert seen == 10
+    # rotate_fwd against the reference's outputs, then the refused offsets
+    for k, row in enumerate(g["rotations"]):
+        arr = g["rot_in_%d" % k].copy()
+        lib.rotate_fwd(arr.ctypes.data_as(vp), int(row["size"]), int(row["offset"]))
+        assert np.array_equal(arr, g["rot_out_%d" % k]), k
+    arr = np.arange(9, dtype=np.int32)
+    lib.rotate_fwd(arr.ctypes.data_as(vp), 9, 10)
+    assert np.array_equal(arr, np.arange(9)) and "rotate_fwd" in fa.last_error()
+    lib.rotate_fwd(arr.ctypes.data_as(vp), 9, -1)
+    assert np.array_equal(arr, np.arange(9))
+    assert lib.gnss_make_replica_dev(None, 4, 0.0, 1.0, vp(out.data_ptr()), None) == fa.ARM_MATH_ARGUMENT_ERROR
+    G.check(lib.gnss_make_replica_dev(vp(cd.data_ptr()), 0, 0.0, 1.0, vp(out.data_ptr()), None))     # empty: no-op
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("doppler,phase,spc,size", [(0.0, 0.0, 4, 4092), (2500.0, 30.0, 4, 4092), (-4999.0, -170.5, 2, 2046), (123.456, 359.0, 4, 16384)])
+def test_mix_prn_vs_oracle(doppler, phase, spc, size):
+    """mix_prn (gnss_codes.c:1032-1063) with a caller-supplied code and phase_deg: host-pointer name and device entry
+    against the oracle's restatement (float-literal PI included).  Parity unpinned by the reference: gnss_codes.c cannot
+    be compiled here; its recursion is the one make_replica shares, which IS pinned."""
+    import torch
+    import gpu_util as G
+    fa, lib = _lib()
+    code = np.resize(H.ca_code(13, spc), size).astype(np.int32)
+    code[5] = 3                                   # any int scales the phasor, not only +-1 (:1046)
+    want = np.zeros((size, 2), np.float32)
+    H.oracle().orc_mix_prn(ptr(code, c_i32), doppler, phase, want.ctypes.data_as(vp), size, spc)
+    got = np.full((size, 2), np.nan, np.float32)
+    lib.mix_prn(code.ctypes.data_as(vp), doppler, phase, got.ctypes.data_as(vp), size, spc)
+    assert np.abs(got - want).max() <= 1.2e-7 * 3
+    assert np.abs(np.delete(got, 5, 0) - np.delete(want, 5, 0)).max() <= 1.2e-7
+    assert (got == want).mean() > 0.999
+    cd = torch.from_numpy(code).cuda()
+    out = torch.zeros((size, 2), device="cuda")
+    G.check(lib.gnss_mix_prn_dev(vp(cd.data_ptr()), doppler, phase, vp(out.data_ptr()), size, spc, G.stream_ptr()))
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), got)
+    # synth_gps_prn = getCode + mix_prn(phase 0) (:1066-1071)
+    if phase == 0.0 and spc == 4:
+        rep = np.zeros((size, 2), np.float32)
+        lib.synth_gps_prn(13, doppler, size, rep.ctypes.data_as(vp), spc)
+        code[5] = H.ca_code(13, spc)[5]
+        lib.mix_prn(code.ctypes.data_as(vp), doppler, 0.0, got.ctypes.data_as(vp), size, spc)
+        assert np.array_equal(rep, got)
+
+
+@pytest.mark.gpu
+def test_reference_named_helpers_on_edge_arguments():
+    """what the reference does on arguments its callers never pass, kept instead of aborting"""
+    fa, lib = _lib()
+    L = H.oracle()
+    row = H.rng(9400).integers(0, 5, 300).astype(np.float32)
+    pk, wk = fa.top2_pks(), H.OrcTop2()
+    # a negative separation: "abs(m - idx1) > pk_sep" holds for every pair of distinct indices, as with 0
+    assert lib.find_top2_peaks_real(row.ctypes.data_as(vp), 300, -5, ctypes.byref(pk), None) == 0
+    assert L.orc_find_top2_peaks_real(row.ctypes.data_as(vp), 300, -5, ctypes.byref(wk)) == 0
+    as_int = lambda v: -1 if v == ctypes.c_size_t(-1).value else int(v)
+    assert (pk.val1, as_int(pk.idx1), pk.val2, as_int(pk.idx2)) == (wk.val1, wk.idx1, wk.val2, wk.idx2)
+    # cov_size <= 5: the reference divides by cov_size - 5 and returns whatever comes out
+    L.orc_compute_snr_real.restype = ctypes.c_double
+    L.orc_compute_snr_real.argtypes = [vp, ctypes.c_int, ctypes.c_double, ctypes.c_int]
+    for n in (0, -3, 3, 5):
+        a = lib.compute_snr_real(row.ctypes.data_as(vp), n, 4.0, 1)
+        b = L.orc_compute_snr_real(row.ctypes.data_as(vp), n, 4.0, 1)
+        assert (np.isnan(a) and np.isnan(b)) or a == b, (n, a, b)
+    assert lib.find_top2_peaks_real(row.ctypes.data_as(vp), 16385, 3, ctypes.byref(pk), None) == -1   # documented limit

@@ -107,3 +107,33 @@ def test_rfft_fixed_edge_cases():
     torch.cuda.synchronize()
     want, _ = orc_rfft("q15", np.full(n, 1000, np.int16), n, 0)
     assert bool((y == torch.from_numpy(want).cuda()[None, :]).all())
+
+
+@pytest.mark.parametrize("kind", ["q15", "q31"])
+@pytest.mark.parametrize("n", [32, 64, 2048])
+def test_rfft_fixed_inverse_from_a_batch_offset(n, kind):
+    """An inverse transform's input is n + 2 scalars (68 bytes for 32 q15 points): a caller that slices a batch
+    (fft_amd.dist.batch_slice) hands over a pointer that is aligned to the point, not to 16 bytes.  Accepted, and the
+    result equals the transforms' share of the whole-batch call."""
+    import torch
+    import fft_amd
+    import gpu_util as G
+    dt = np.int16 if kind == "q15" else np.int32
+    amp = 1 << (14 if kind == "q15" else 30)
+    batch, b0 = 9, 3
+    x = H.rng(9900 + n).integers(-amp, amp, (batch, n + 2)).astype(dt)
+    whole = _dev(kind, x, n, 1, 1)
+    S = _inst(kind, n, 1, 1)
+    t = torch.from_numpy(x).cuda()
+    out = torch.zeros((batch - b0, n), dtype=t.dtype, device="cuda")
+    src = t.data_ptr() + b0 * (n + 2) * t.element_size()
+    assert src % 16 != 0
+    G.check(getattr(fft_amd.lib, "arm_rfft_%s_dev" % kind)(ctypes.byref(S), ctypes.c_void_p(src), ctypes.c_void_p(out.data_ptr()),
+                                                          batch - b0, G.stream_ptr()))
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), whole[b0:])
+    # the forward source keeps its 16-byte requirement (16-byte loads)
+    Sf = _inst(kind, n, 0, 1)
+    o2 = torch.zeros((1, 2 * n), dtype=t.dtype, device="cuda")
+    assert getattr(fft_amd.lib, "arm_rfft_%s_dev" % kind)(ctypes.byref(Sf), ctypes.c_void_p(t.data_ptr() + t.element_size() * 2),
+                                                         ctypes.c_void_p(o2.data_ptr()), 1, None) == fft_amd.ARM_MATH_ARGUMENT_ERROR

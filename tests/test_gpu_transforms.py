@@ -236,7 +236,7 @@ def test_cfft_q15_bit_exact(n, ifft):
     x[2, :] = -32768
     for bitrev in (1, 0):
         want = x.copy()
-        assert H.oracle().orc_cfft_q15_batch(ptr(want, c_i16), n, batch, ifft, bitrev, 0) == 0
+        assert H.oracle().orc_cfft_q15_batch(ptr(want, c_i16), n, batch, ifft, bitrev, H.default_tw_rule(n)) == 0
         got = G.cfft_dev("q15", x, n, ifft, bitrev)
         assert np.array_equal(got, want), "q15 N=%d ifft=%d bitrev=%d: %d words differ" % (n, ifft, bitrev, (got != want).sum())
 
@@ -253,7 +253,7 @@ def test_cfft_q31_bit_exact(n, ifft):
     x[2, :] = -2 ** 31
     for bitrev in (1, 0):
         want = x.copy()
-        assert H.oracle().orc_cfft_q31_batch(ptr(want, c_i32), n, batch, ifft, bitrev, 0) == 0
+        assert H.oracle().orc_cfft_q31_batch(ptr(want, c_i32), n, batch, ifft, bitrev, H.default_tw_rule(n)) == 0
         got = G.cfft_dev("q31", x, n, ifft, bitrev)
         assert np.array_equal(got, want), "q31 N=%d ifft=%d bitrev=%d: %d words differ" % (n, ifft, bitrev, (got != want).sum())
 

@@ -42,9 +42,67 @@ def test_synth_gps_prn_phase_progression():
     rep = np.zeros((4092, 2), np.float32)
     H.oracle().orc_synth_gps_prn(1, 1000.0, 4092, rep.ctypes.data_as(ctypes.c_void_p), 4)
     z = (rep[:, 0] + 1j * rep[:, 1]) * H.ca_code(1, 4)
-    want = np.exp(2j * np.pi * 1000.0 * np.arange(4092) / 4.092e6)
-    assert np.abs(z - want).max() < 2e-7
+    ref_pi = float(np.float32(3.14159265358979))      # mix_prn's PI is the FLOAT literal of Include/gnss_codes.h:33
+    want = np.exp(2j * ref_pi * 1000.0 * np.arange(4092) / 4.092e6)
+    assert np.abs(z - want).max() < 1.2e-7
+    assert np.abs(z - np.exp(2j * np.pi * 1000.0 * np.arange(4092) / 4.092e6)).max() > 1.5e-7   # ... and that is visible
     assert abs(z[1] - (0.999999 + 0.001535j)) < 1e-6                                # the value SURVEY 8(c) records
+
+
+# ---- make_replica / rotate_fwd: the one GNSS piece the reference itself pins (quasi_pilot_tests.c compiles unmodified) ----
+def _replica_cases():
+    g = H.golden_replicas()
+    for k, row in enumerate(g["cases"]):
+        yield k, row, g["code_%d" % k].astype(np.int32), g["replica_%d" % k]
+
+
+def test_make_replica_oracle_equals_reference_fixtures():
+    """orc_make_replica against the outputs of the reference's own object code (tests/golden/gnss_replica.npz)."""
+    n_cases = 0
+    for k, row, code, want in _replica_cases():
+        got = np.zeros_like(want)
+        H.oracle().orc_make_replica(code.ctypes.data_as(ctypes.c_void_p), got.ctypes.data_as(ctypes.c_void_p),
+                                    float(row["doppler"]), int(row["size"]), float(row["samp_freq"]))
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (k, row)
+        n_cases += 1
+    assert n_cases == 10
+    g = H.golden_replicas()
+    for k, row in enumerate(g["rotations"]):
+        arr = g["rot_in_%d" % k].copy()
+        assert H.oracle().orc_rotate_fwd(arr.ctypes.data_as(ctypes.c_void_p), int(row["size"]), int(row["offset"])) == 0
+        assert np.array_equal(arr, g["rot_out_%d" % k])
+
+
+@pytest.mark.skipif(H.ref_quasi() is None, reason="oracle/_ref/libquasi_ref.so not built (reference not mounted)")
+def test_make_replica_fixtures_are_what_the_reference_returns_here():
+    """the committed fixtures, regenerated: the reference's quasi_pilot_tests.c compiled here returns them bit for bit"""
+    Q = H.ref_quasi()
+    for k, row, code, want in _replica_cases():
+        got = np.zeros_like(want)
+        Q.make_replica(code.ctypes.data_as(ctypes.c_void_p), got.ctypes.data_as(ctypes.c_void_p), float(row["doppler"]),
+                       int(row["size"]), float(row["samp_freq"]))
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), k
+    r = H.rng(11)
+    for size, off in ((1, 0), (1, 1), (100, 37), (4092, 2047)):
+        arr = r.integers(-5, 5, size).astype(np.int32)
+        a, b = arr.copy(), arr.copy()
+        Q.rotate_fwd(a.ctypes.data_as(ctypes.c_void_p), size, off)
+        assert H.oracle().orc_rotate_fwd(b.ctypes.data_as(ctypes.c_void_p), size, off) == 0
+        assert np.array_equal(a, b) and np.array_equal(a, np.roll(arr, off))
+
+
+def test_mix_prn_is_make_replica_with_the_float_pi():
+    """mix_prn (gnss_codes.c:1032-1063) and make_replica share the recursion; they differ in the phase argument, the sample
+    rate (1.023e6 * spc against the caller's) and in PI (float literal against M_PI)"""
+    code = H.ca_code(9, 4)
+    a, b = np.zeros((4092, 2), np.float32), np.zeros((4092, 2), np.float32)
+    H.oracle().orc_mix_prn(ptr(code, c_i32), 0.0, 0.0, a.ctypes.data_as(ctypes.c_void_p), 4092, 4)
+    assert np.array_equal(a[:, 0], code.astype(np.float32)) and not a[:, 1].any()
+    H.oracle().orc_mix_prn(ptr(code, c_i32), 2500.0, 30.0, a.ctypes.data_as(ctypes.c_void_p), 4092, 4)
+    ref_pi = float(np.float32(3.14159265358979))
+    n = np.arange(4092)
+    want = code * np.exp(1j * (30.0 * ref_pi / 180.0 + 2.0 * ref_pi * 2500.0 / 4.092e6 * n))
+    assert np.abs((a[:, 0] + 1j * a[:, 1]) - want).max() < 1.2e-7
 
 
 def _top2(x, sep):

@@ -48,7 +48,7 @@ def test_rfft_f32_golden(n, sig):
     H.assert_close_error(out, x, 5.0e-5, 1.0e-5)
 
 
-@pytest.mark.parametrize("rounding", [0, 1])
+@pytest.mark.parametrize("rounding", [0, 1, 2])
 @pytest.mark.parametrize("sig", ["noisy", "step"])
 @pytest.mark.parametrize("n", CFFT_SIZES)
 def test_cfft_q15_golden(n, sig, rounding):
@@ -64,7 +64,7 @@ def test_cfft_q15_golden(n, sig, rounding):
     assert np.abs(y.astype(np.int32) - want_i.astype(np.int32)).max() <= 15
 
 
-@pytest.mark.parametrize("rounding", [0, 1])
+@pytest.mark.parametrize("rounding", [0, 1, 2])
 @pytest.mark.parametrize("sig", ["noisy", "step"])
 @pytest.mark.parametrize("n", CFFT_SIZES)
 def test_cfft_q31_golden(n, sig, rounding):
@@ -72,7 +72,15 @@ def test_cfft_q31_golden(n, sig, rounding):
     y = x.copy()
     assert H.oracle().orc_cfft_q31(ptr(y, c_i32), n, 0, 1, rounding) == 0
     assert H.snr_db(want, y) >= 90.0
-    assert np.abs(y.astype(np.int64) - want.astype(np.int64)).max() <= 53
+    err = np.abs(y.astype(np.int64) - want.astype(np.int64)).max()
+    if rounding == 2 and sig == "step" and n >= 128:
+        # The fork's generator (CMSIS/CMSIS.cpp:445-458: FLOAT angle, float product, 24 significant bits per q31 entry)
+        # MISSES the reference's own 53-LSB bound (TransformCQ31.cpp:6-7) on the forward Step patterns from 128 points
+        # up (58 ... 160 LSB on the 0.9-high DC bin): evidence that the reference's tables for the sizes its tests cover
+        # were not printed by that function.  Held here so that the fact stays checked; SNR >= 90 dB still holds.
+        assert 53 < err <= 200
+    else:
+        assert err <= 53
     y = xin.copy()
     assert H.oracle().orc_cfft_q31(ptr(y, c_i32), n, 1, 1, rounding) == 0
     want_i = x >> int(np.log2(n))

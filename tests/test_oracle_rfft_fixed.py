@@ -13,13 +13,13 @@ from helpers import c_i16, c_i32, ptr
 RSIZES = [32, 64, 128, 256, 512, 1024, 2048, 4096]
 
 
-def orc_rfft(kind, x, n, ifft, bitrev=1, L=None):
+def orc_rfft(kind, x, n, ifft, bitrev=1, L=None, tw_rule=0):
     L = L or H.oracle()
     dt, ct = (np.int16, c_i16) if kind == "q15" else (np.int32, c_i32)
     src = np.ascontiguousarray(x, dt).copy()
     dst = np.zeros(n if ifft else 2 * n, dt)
     fn = getattr(L, ("orc_rfft_" if L is H.oracle() else "ref_rfft_") + kind)
-    args = (ptr(src, ct), ptr(dst, ct), n, ifft, bitrev) + ((0,) if L is H.oracle() else ())
+    args = (ptr(src, ct), ptr(dst, ct), n, ifft, bitrev) + ((tw_rule,) if L is H.oracle() else ())
     assert fn(*args) == 0
     return dst, src
 

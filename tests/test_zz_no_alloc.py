@@ -30,12 +30,16 @@ def test_noalloc_four_step_equals_the_workspace_entry_point_twice_in_a_row():
     import gpu_util as G
     lib = fa.lib
     big, small = 1 << 20, 1 << 16
-    # not prepared yet on this device (unless an earlier test did): a missing plan is refused, nothing is allocated
+    # 2^19 points: nothing calls arm_cfft_u32_f32_noalloc_prepare for this size, so the call is refused -- also when
+    # arm_cfft_u32_f32_dev has already built twiddle tables for it (done here on purpose): tables are not a prepared plan
     S = fa.arm_cfft_instance_u32_f32()
     G.check(lib.arm_cfft_init_u32_f32(ctypes.byref(S), 1 << 19))
     t = torch.zeros(2 << 19, device="cuda")
-    if lib.arm_cfft_u32_f32_noalloc_dev(ctypes.byref(S), ctypes.c_void_p(t.data_ptr()), 1, 0, None) != 0:
-        assert "noalloc_prepare" in fa.last_error()
+    wk = torch.empty_like(t)
+    G.check(lib.arm_cfft_u32_f32_dev(ctypes.byref(S), ctypes.c_void_p(t.data_ptr()), ctypes.c_void_p(wk.data_ptr()), 1, 0, G.stream_ptr()))
+    torch.cuda.synchronize()
+    assert lib.arm_cfft_u32_f32_noalloc_dev(ctypes.byref(S), ctypes.c_void_p(t.data_ptr()), 1, 0, None) == fa.ARM_MATH_ARGUMENT_ERROR
+    assert "noalloc_prepare" in fa.last_error()
     for n in (big, small):
         G.check(lib.arm_cfft_u32_f32_noalloc_prepare(n))
     # first call: 2^20 x 8 = the whole 64 MiB workspace; second call: a smaller transform and batch that reuses its start
