@@ -729,6 +729,155 @@ __global__ __launch_bounds__(DirectPlan<LOGN>::WG) void cfft_fixed_direct_kernel
   for (int c = 0; c < 16; c++) DirectIo<Q>::store(Q::pack(direct_out<Q, LOGN>(x[c])), rs, voff, direct_rc(c) * T * W);
 }
 
+// ------------------------------------------------------------------------------------------
+// q31, 8192 / 16384 points: the direct form with a HALF-FOOTPRINT exchange (the f32 kernels' SPLIT, fft_core_f32.hpp).
+// Above, a q31 image is N 8-byte words: 128 KiB at 16384 points, ONE 1024-thread workgroup per CU, whose load, transform and
+// store phases then have nothing to overlap with (SQ_WAIT_INST_ANY = half of all wave-cycles, profiles/r02_pmc_sq_cfft_q31.txt).
+// Here the points stay in REGISTERS from step to step and the image holds N 32-bit words: every exchange between two steps
+// runs twice through it, real parts then imaginary parts (write re | barrier | read re | barrier | write im | barrier |
+// read im), addressed exactly as the in-place steps above address their words -- a step's outputs leave through ITS map,
+// the next step's inputs arrive through the next map, so the bank behaviour of both is what dlane_map arranged.  Three
+// barriers more per exchange, half the image: two 1024-thread workgroups per CU at 16384 points, three 512-thread ones at
+// 8192.  Stages, order and rounding are the same functions (bfly, by2, StageKind): the result does not change by a bit.
+// Twiddles of the stages whose table index is a multiple of 2^TLS come from an LDS copy of every 2^TLS-th entry (TLS = 2:
+// the quarter table, 12 KiB at 8192; TLS = 4 at 16384, 6 KiB -- the quarter table would push the workgroup past 80 KiB), the
+// others from the global table (L2).
+// ------------------------------------------------------------------------------------------
+template <int LOGN>
+struct SplitQ31 {
+  using PL = DirectPlan<LOGN>;
+  static constexpr int TLS = LOGN >= 14 ? 4 : 2;
+  static constexpr int TL_ENTRIES = (3 * PL::N / 4) >> TLS;
+  static constexpr size_t LDS_BYTES = (size_t)PL::LDS_WORDS * sizeof(int32_t) + (size_t)TL_ENTRIES * sizeof(int2);
+  static constexpr int MINW = LOGN >= 14 ? 8 : (LOGN == 13 ? 6 : 7);   // waves per SIMD the register budget is cut for (2 x 16 / 3 x 8 waves per CU ... per SIMD)
+};
+
+// one exchange: x[c] leaves as word baseA + doff(c, LOGQA), x[c] returns as word baseB + doff(c, LOGQB)
+template <int LOGN, int LOGQA, int LOGQB>
+__device__ __forceinline__ void q31_exchange(int32_t *lds, int baseA, int baseB, Q31::cpx *x)
+{
+  using PL = DirectPlan<LOGN>;
+#pragma unroll
+  for (int c = 0; c < 16; c++) lds[baseA + PL::doff(c, LOGQA)] = x[c].re;
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < 16; c++) x[c].re = lds[baseB + PL::doff(c, LOGQB)];
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < 16; c++) lds[baseA + PL::doff(c, LOGQA)] = x[c].im;
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < 16; c++) x[c].im = lds[baseB + PL::doff(c, LOGQB)];
+}
+
+// steps from stage S on, the points in registers; (baseP, LOGQP) = where the previous step's outputs belong
+template <int LOGN, int S, bool INV, int LOGQP, bool FIRST>
+__device__ __forceinline__ void q31_split_steps(Q31::cpx *x, int32_t *lds, const int2 *tl, const int2 *__restrict__ tw, int tid, int baseP)
+{
+  using PL = DirectPlan<LOGN>;
+  constexpr int TLS = SplitQ31<LOGN>::TLS;
+  auto tg = [&](int ic) { return tw[ic]; };
+  auto tld = [&](int ic) { return tl[ic >> TLS]; };
+  if constexpr (!FIRST) __syncthreads();   // every thread has read the previous exchange's imaginary parts
+  if constexpr (S < PL::M - 2) {
+    constexpr bool PAIR = ((PL::M - 2 - S) % 2) == 0;
+    constexpr int LOGN1 = PL::LOGL - 2 * S, LOGQ = LOGN1 - 4;
+    constexpr bool LDS_S = ((PL::TWMOD0 << (2 * S)) & ((1 << TLS) - 1)) == 0;        // stage S's indices are multiples of 2^TLS
+    int blk, j;
+    dlane_map<LOGN, LOGN1>(tid, blk, j);
+    const int base = PL::pad((blk << LOGN1) + j);
+    q31_exchange<LOGN, LOGQP, LOGQ>(lds, baseP, base, x);
+    if constexpr (PAIR) {
+      if constexpr (LDS_S) pair_butterflies<Q31, PL::LOGL, S, INV, PL::TWMOD0>(x, j, tld, tld);
+      else pair_butterflies<Q31, PL::LOGL, S, INV, PL::TWMOD0>(x, j, tg, tld);       // stage S + 1: multiples of 4 * 2^TLS at least
+    } else {
+      if constexpr (LDS_S) stage_butterflies<Q31, PL::LOGL, S, INV, PL::TWMOD0>(x, j, tld);
+      else stage_butterflies<Q31, PL::LOGL, S, INV, PL::TWMOD0>(x, j, tg);
+    }
+    q31_split_steps<LOGN, S + (PAIR ? 2 : 1), INV, LOGQ, false>(x, lds, tl, tw, tid, base);
+  } else {
+    // last step: block brev(tid); stage M-2 of the pair has uniform twiddles (j = 0): scalar loads from the global table
+    const int blk = (int)(__brev((unsigned)tid) >> (32 - PL::LOGT));
+    q31_exchange<LOGN, LOGQP, 0>(lds, baseP, PL::pad(blk << 4), x);
+    pair_butterflies<Q31, PL::LOGL, PL::M - 2, INV, PL::TWMOD0>(x, 0, tg, tg);
+  }
+}
+
+template <int LOGN, bool INV>
+__global__ __launch_bounds__(DirectPlan<LOGN>::T, SplitQ31<LOGN>::MINW) void cfft_q31_split_kernel(int2 *__restrict__ data,
+                                                                                                  const int2 *__restrict__ tw, uint32_t batch)
+{
+  using PL = DirectPlan<LOGN>;
+  using SP = SplitQ31<LOGN>;
+  using cpx = Q31::cpx;
+  static_assert(PL::TPB == 1 && LOGN >= 12 && LOGN <= 14, "one transform per workgroup");
+  static_assert(LOGN != 14 || (1 << SP::TLS) <= 16, "stage 2 onwards indexes the table in multiples of 16");
+  constexpr int W = sizeof(int2), T = PL::T, M = PL::M;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const uint32_t t0 = blockIdx.x + blockIdx.y * gridDim.x;
+  if (t0 >= batch) return;
+  const int tid = threadIdx.x;
+  int32_t *lds = reinterpret_cast<int32_t *>(lds_raw);
+  int2 *tl = reinterpret_cast<int2 *>(lds + PL::LDS_WORDS);
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(data + (size_t)t0 * PL::N, 0, (int)(PL::N * W), 0x00020000);
+  const int voff = tid * W;
+  cpx x[16];
+#pragma unroll
+  for (int c = 0; c < 16; c++) x[c] = Q31::unpack(DirectIo<Q31>::load(rs, voff, c * T * W));
+  for (int i = tid; i < SP::TL_ENTRIES; i += T) tl[i] = tw[i << SP::TLS];
+  // ---- first step on the loaded registers (as direct_transform) ----
+  constexpr int S1 = (PL::BY2 || (M & 1)) ? 1 : 2;
+  if constexpr (PL::BY2) {
+#pragma unroll
+    for (int c = 0; c < 8; c++) by2<Q31, INV>(x[c], x[c + 8], Q31::unpack(tw[tid + c * T]));
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        cpx y[4] = {x[8 * h + k], x[8 * h + k + 2], x[8 * h + k + 4], x[8 * h + k + 6]};
+        const int ic = 2 * (tid + k * T);
+        bfly<Q31, 0, INV>(y, Q31::unpack(tw[ic]), Q31::unpack(tw[2 * ic]), Q31::unpack(tw[3 * ic]));
+        x[8 * h + k] = y[0]; x[8 * h + k + 2] = y[1]; x[8 * h + k + 4] = y[2]; x[8 * h + k + 6] = y[3];
+      }
+    }
+  } else if constexpr ((M & 1) == 0) {
+    auto tg = [&](int ic) { return tw[ic]; };
+    pair_butterflies<Q31, LOGN, 0, INV, 1>(x, tid, tg, tg);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      cpx y[4] = {x[k], x[4 + k], x[8 + k], x[12 + k]};
+      const int ic = tid + k * T;
+      bfly<Q31, 0, INV>(y, Q31::unpack(tw[ic]), Q31::unpack(tw[2 * ic]), Q31::unpack(tw[3 * ic]));
+      x[k] = y[0]; x[4 + k] = y[1]; x[8 + k] = y[2]; x[12 + k] = y[3];
+    }
+  }
+  // ---- the remaining steps, an exchange before each ----
+  q31_split_steps<LOGN, S1, INV, PL::LOGT, true>(x, lds, tl, tw, tid, PL::pad(tid));
+#pragma unroll
+  for (int c = 0; c < 16; c++) DirectIo<Q31>::store(Q31::pack(direct_out<Q31, LOGN>(x[c])), rs, voff, direct_rc(c) * T * W);
+}
+
+template <int LOGN, bool INV>
+static hipError_t launch_q31_split(int2 *data, const int2 *tw, uint32_t batch, hipStream_t stream)
+{
+  using PL = DirectPlan<LOGN>;
+  constexpr size_t lds_bytes = SplitQ31<LOGN>::LDS_BYTES;
+  static std::atomic<bool> attr_done[16];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  auto kern = cfft_q31_split_kernel<LOGN, INV>;
+  if (lds_bytes > 48 * 1024 && (dev < 0 || dev >= 16 || !attr_done[dev])) {
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 16) attr_done[dev] = true;
+  }
+  const uint32_t gx = batch < 65536u ? batch : 65536u, gy = (batch + gx - 1) / gx;
+  note_kernel(INV ? "cfft_q31_split_kernel<%d, true>" : "cfft_q31_split_kernel<%d, false>", false, LOGN);
+  kern<<<dim3(gx, gy, 1), PL::T, lds_bytes, stream>>>(data, tw, batch);
+  return hipGetLastError();
+}
+
 // rocprof's spelling of a fixed-point kernel instance, for note_kernel (Q15 packs a point into one 32-bit word)
 #define ARMFFT_KNAME_Q(base)                                                                                                   \
   (sizeof(typename Q::word) == 4 ? (INV ? base "<armfft::Q15, %d, true>" : base "<armfft::Q15, %d, false>")                     \
@@ -841,6 +990,17 @@ static hipError_t launch_fixed(int logn, typename Q::word *data, const typename 
 {
   if (batch == 0) return hipSuccess;
   if (bitrev) {
+    if constexpr (sizeof(typename Q::word) == 8) {
+      // q31, 4096 ... 16384 points: the half-footprint exchange (same-box A/B against the direct form above: 4096 0.654 ->
+      // 0.660 of the roofline, 8192 0.625 -> 0.665, 16384 0.421 -> 0.526)
+      if (logn >= 12 && logn <= 14) {
+        int2 *d = reinterpret_cast<int2 *>(data);
+        const int2 *t = reinterpret_cast<const int2 *>(tw);
+        if (logn == 12) return inverse ? launch_q31_split<12, true>(d, t, batch, stream) : launch_q31_split<12, false>(d, t, batch, stream);
+        if (logn == 13) return inverse ? launch_q31_split<13, true>(d, t, batch, stream) : launch_q31_split<13, false>(d, t, batch, stream);
+        return inverse ? launch_q31_split<14, true>(d, t, batch, stream) : launch_q31_split<14, false>(d, t, batch, stream);
+      }
+    }
     switch (logn) {
 #define D(L) \
   case L: return inverse ? launch_fixed_direct<Q, L, true>(data, tw, batch, stream) : launch_fixed_direct<Q, L, false>(data, tw, batch, stream);
