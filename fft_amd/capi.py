@@ -6,7 +6,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int
 
 __all__ = [
     "lib", "lib_path", "ARM_MATH_SUCCESS", "ARM_MATH_ARGUMENT_ERROR",
-    "arm_rfft_instance_q15", "arm_rfft_instance_q31", "gnss_acq_result", "gnss_top2", "top2_pks", "iq_resamp_zp_t", "bb_meas_t", "bb_meas_sat_t", "SYS_GPS", "SYS_GAL", "arm_cfft_radix2_instance_f32", "arm_cfft_instance_u32_f32", "arm_cfft_instance_f32", "arm_cfft_instance_q15", "arm_cfft_instance_q31", "arm_rfft_fast_instance_f32",
+    "arm_rfft_instance_q15", "arm_rfft_instance_q31", "gnss_acq_result", "gnss_refine_result", "gnss_top2", "top2_pks", "iq_resamp_zp_t", "bb_meas_t", "bb_meas_sat_t", "SYS_GPS", "SYS_GAL", "arm_cfft_radix2_instance_f32", "arm_cfft_instance_u32_f32", "arm_cfft_instance_f32", "arm_cfft_instance_q15", "arm_cfft_instance_q31", "arm_rfft_fast_instance_f32",
     "last_error", "EXPORTED_SYMBOLS",
 ]
 
@@ -73,6 +73,10 @@ class bb_meas_t(Structure):          # Include/msb_funcs.h:35-40
 SYS_GPS, SYS_GAL = 1, 2
 
 
+class gnss_refine_result(Structure):
+    _fields_ = [("phase_deg", c_double), ("pwr", c_float), ("doppler", c_float), ("best_off", c_int32), ("reserved", c_int32)]
+
+
 class gnss_top2(Structure):
     _fields_ = [("val1", c_float), ("idx1", c_int32), ("val2", c_float), ("idx2", c_int32)]
 
@@ -115,6 +119,7 @@ EXPORTED_SYMBOLS = (
     + ["write_bb_msb", "read_bb_msb", "gnss_acq_to_meas", "gnss_acq_plan_create_replicas", "gnss_l5_generate_I_dev"]
     + ["gnss_e1b_cboc_replica_dev", "gnss_hexstream_to_chips", "gnss_acquire_multi"]
     + ["gnss_mix_prn_dev", "gnss_make_replica_dev", "gnss_rotate_fwd_dev", "mix_prn", "make_replica", "rotate_fwd"]
+    + ["gnss_refine_dev", "recover_prn_phase_deg_with_doppler", "gnss_meas_refine"]
     + ["getCode", "synth_gps_prn", "find_top2_peaks_cplx", "find_top2_peaks_real", "compute_snr_cplx", "compute_snr_real", "InterpolateCodePhase"]
     + ["iq_resamp_zp_init", "iq_resamp_process_zero_phase", "iq_resamp_zp_free"]
     + ["arm_fft_mi355_set_device", "arm_fft_mi355_warm", "arm_fft_mi355_last_error", "arm_fft_mi355_last_kernel",
@@ -223,6 +228,11 @@ def _load():
     L.gnss_mix_prn_dev.argtypes, L.gnss_mix_prn_dev.restype = [c_void_p, dbl, dbl, c_void_p, u32, i32, c_void_p], c_int
     L.gnss_make_replica_dev.argtypes, L.gnss_make_replica_dev.restype = [c_void_p, u32, c_float, c_float, c_void_p, c_void_p], c_int
     L.gnss_rotate_fwd_dev.argtypes, L.gnss_rotate_fwd_dev.restype = [c_void_p, c_void_p, u32, i32, c_void_p], c_int
+    L.gnss_refine_dev.argtypes = [c_void_p, u32, u32, c_void_p, c_void_p, c_void_p, dbl, u32, c_void_p, c_void_p]
+    L.gnss_refine_dev.restype = c_int
+    L.recover_prn_phase_deg_with_doppler.argtypes = [c_void_p, c_int, c_void_p, c_int, dbl, dbl, POINTER(c_int), POINTER(c_float), POINTER(c_float)]
+    L.recover_prn_phase_deg_with_doppler.restype = dbl
+    L.gnss_meas_refine.argtypes, L.gnss_meas_refine.restype = [c_void_p, u32, i32, dbl, i32, POINTER(bb_meas_t), c_void_p], c_int
     L.mix_prn.argtypes, L.mix_prn.restype = [c_void_p, dbl, dbl, c_void_p, c_int, c_int], None
     L.make_replica.argtypes, L.make_replica.restype = [c_void_p, c_void_p, c_float, c_int, c_float], None
     L.rotate_fwd.argtypes, L.rotate_fwd.restype = [c_void_p, c_int, c_int], None

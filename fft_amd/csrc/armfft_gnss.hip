@@ -532,6 +532,138 @@ __global__ __launch_bounds__(256) void gnss_snr_kernel(const float *__restrict__
 }
 
 // ------------------------------------------------------------------------------------------
+// fine search: recover_prn_phase_deg_with_doppler (CMSIS/CMSIS.cpp:362-434) -- around an acquired (code offset, Doppler)
+// the reference wipes the carrier at doppler + f, f = -1, 0, +1 Hz, with a FLOAT recursive phasor (no renormalisation,
+// :391-404), correlates the wiped millisecond against the code at every offset within +-10 samples of the acquired one
+// (double sums of float products, :407-416) and keeps the largest |sum| -- first one wins among equals, f outer / offset
+// inner, both ascending -- returning atan2(im, re) in degrees, the offset, f and the power.
+// One workgroup per satellite.  The three phasor recursions are sequential by construction (each step rounds to float),
+// so three lanes run them, one each, with the reference's operations in the reference's order (no contraction) and leave
+// the phasors in LDS; all threads then wipe (two float products and a float sum per component, as :396-397) and every wave
+// takes its share of the 3 x 21 dot products.  The double sums are accumulated per lane and combined by a tree, not in
+// the reference's index order: they agree with it to ~1e-13 relative, the offset / f decisions are the reference's.
+// ------------------------------------------------------------------------------------------
+constexpr int kRefineSpan = 10, kRefineOffs = 2 * kRefineSpan + 1, kRefineF = 3, kRefineMaxSize = 1023 * 4;   // static float iw[1023 * 4] (:392)
+__host__ __device__ constexpr size_t refine_res_offset(int size) { return (((size_t)kRefineF * size * 8 + (size_t)size * 4) + 15) & ~(size_t)15; }
+__host__ __device__ constexpr size_t refine_lds_bytes(int size) { return refine_res_offset(size) + (size_t)kRefineF * kRefineOffs * 2 * sizeof(double); }
+
+__global__ __launch_bounds__(256) void gnss_refine_kernel(const float2 *__restrict__ sig, int sig_stride, const int32_t *__restrict__ codes, int size,
+                                                          const int32_t *__restrict__ code_offsets, const double *__restrict__ dopplers,
+                                                          double sample_rate, gnss_refine_result *__restrict__ out)
+{
+  // The reference's float expressions round after every product (MSVC / gcc without contraction).  Under the library's
+  // -ffp-contract=fast the backend fuses a product into the sum that follows it whatever the source says (HIP's __fmul_rn is
+  // a plain operator, a contract(off) pragma only clears per-instruction flags that =fast does not consult; seen: the
+  // recursion drifts by 2e-6 over a millisecond).  rnd() hands the rounded product through an empty asm the combiner cannot
+  // look into.
+  auto rnd = [](float v) { asm volatile("" : "+v"(v)); return v; };
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  float2 *wq = reinterpret_cast<float2 *>(lds_raw);                       // [3][size] (iw, qw) per f
+  float *code = reinterpret_cast<float *>(wq + kRefineF * size);            // [size], the ints as the floats the products see (:414)
+  double *res = reinterpret_cast<double *>(lds_raw + refine_res_offset(size));   // [63][2]
+  const int tid = threadIdx.x, sat = blockIdx.x;
+  const float2 *__restrict__ x = sig + (size_t)sat * sig_stride;
+  const int32_t *__restrict__ prn = codes + (size_t)sat * size;
+  const double fd = dopplers[sat];
+  const int code_offset = code_offsets[sat];
+  if (tid < kRefineF) {
+    const float f = -1.0f + (float)tid;                                     // :384: f = -span; f <= +span + 1e-3f; f += step
+    const double dtheta = 2.0 * (double)kRefPiF * (fd + (double)f) / sample_rate;   // :386 (PI is the float literal)
+    const float c_inc = (float)cos(dtheta), s_inc = (float)sin(dtheta);
+    float pc = 1.0f, ps = 0.0f;
+    float2 *w = wq + tid * size;
+    for (int n = 0; n < size; n++) {
+      w[n] = make_float2(pc, ps);
+      const float npc = rnd(pc * c_inc) - rnd(ps * s_inc);      // :399-400
+      const float nps = rnd(pc * s_inc) + rnd(ps * c_inc);
+      pc = npc;
+      ps = nps;
+    }
+  }
+  for (int n = tid; n < size; n += 256) code[n] = (float)prn[n];
+  __syncthreads();
+  for (int e = tid; e < kRefineF * size; e += 256) {
+    const int n = e % size;
+    const float2 p = wq[e], v = x[n];
+    // (I + jQ) e^{-j theta}: iw = +I pc + Q ps, qw = -I ps + Q pc (:396-397), each product and sum rounded to float
+    const float iw = rnd(+v.x * p.x) + rnd(v.y * p.y), qw = rnd(-v.x * p.y) + rnd(v.y * p.x);
+    wq[e] = make_float2(iw, qw);
+  }
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6;
+  for (int combo = wave; combo < kRefineF * kRefineOffs; combo += 4) {
+    const int fi = combo / kRefineOffs;
+    int off = code_offset - kRefineSpan + combo % kRefineOffs;
+    off = ((off % size) + size) % size;
+    const float2 *w = wq + fi * size;
+    double re = 0.0, im = 0.0;
+    for (int n = lane; n < size; n += 64) {
+      int idx = n - off;
+      if (idx < 0) idx += size;                                              // :412-413
+      const float c = code[idx];
+      const float pr = rnd(w[n].x * c), pi = rnd(w[n].y * c);                // float product, double sum (:414-415)
+      re += (double)pr;
+      im += (double)pi;
+    }
+    for (int d = 32; d > 0; d >>= 1) {
+      re += __shfl_xor(re, d);
+      im += __shfl_xor(im, d);
+    }
+    if (lane == 0) {
+      res[2 * combo] = re;
+      res[2 * combo + 1] = im;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    // the reference's visiting order: f ascending, then off = 0 .. size-1 ascending over the offsets inside the window --
+    // a window that wraps past either end of the code period (:378-380, :408-409) is visited low offsets first
+    // the window exactly as :376-380 builds it
+    float code_low = (float)code_offset - (float)kRefineSpan, code_high = (float)code_offset + (float)kRefineSpan;
+    int wrap = 0;
+    if (code_low < 0) { code_low += (float)size; wrap = 1; }
+    if (code_high > (float)size) { code_high -= (float)size; wrap = 1; }
+    double best_pow = -1.0, best_re = 0.0, best_im = 0.0, best_f = 0.0;
+    int best_off = 0;
+    const int lo = code_offset - kRefineSpan;
+    for (int fi = 0; fi < kRefineF; fi++) {
+      // offsets of the window in ascending order of the wrapped value
+      int first = 0;   // index k (0..20) of the smallest wrapped offset
+      {
+        int min_off = size;
+        for (int k = 0; k < kRefineOffs; k++) {
+          const int o = (((lo + k) % size) + size) % size;
+          if (o < min_off) { min_off = o; first = k; }
+        }
+      }
+      for (int kk = 0; kk < kRefineOffs; kk++) {
+        const int k = (first + kk) % kRefineOffs;
+        const int combo = fi * kRefineOffs + k;
+        const float off = (float)((((lo + k) % size) + size) % size);
+        if (wrap == 0 && (off < code_low || off > code_high)) continue;        // :408
+        if (wrap == 1 && (off > code_high && off < code_low)) continue;         // :409
+        const double re = res[2 * combo], im = res[2 * combo + 1];
+        const double pw = sqrt(re * re + im * im);
+        if (pw > best_pow) {                                                  // :418: strict, the first of equals stays
+          best_pow = pw;
+          best_f = (double)(-1.0f + (float)fi);
+          best_re = re;
+          best_im = im;
+          best_off = (((lo + k) % size) + size) % size;
+        }
+      }
+    }
+    gnss_refine_result r;
+    r.phase_deg = atan2(best_im, best_re) * (double)(180.0f / kRefPiF);      // :432, R2D = (180.0f / 3.14159265358979f)
+    r.pwr = (float)best_pow;
+    r.doppler = (float)best_f;
+    r.best_off = best_off;
+    r.reserved = 0;
+    out[sat] = r;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // code spectra: C_p = FFT(code p sampled at spc samples per chip, spm samples, zero-padded)
 // ------------------------------------------------------------------------------------------
 template <int LOGN>
@@ -1399,6 +1531,31 @@ arm_status gnss_rotate_fwd_dev(const int32_t *in_dev, int32_t *out_dev, uint32_t
   return hip_ok(hipGetLastError(), "gnss_rotate_kernel") ? ARM_MATH_SUCCESS : ARM_MATH_ARGUMENT_ERROR;
 }
 
+// recover_prn_phase_deg_with_doppler (CMSIS/CMSIS.cpp:362-434) for n_sat satellites at once: satellite k searches
+// signal_dev + k * signal_stride (size complex samples; stride 0 = every satellite searches the same millisecond) with
+// code k (size ints) around code_offsets_dev[k] / dopplers_dev[k]
+arm_status gnss_refine_dev(const float *signal_dev, uint32_t signal_stride, uint32_t size, const int32_t *codes_dev, const int32_t *code_offsets_dev,
+                           const double *dopplers_dev, double sample_rate_hz, uint32_t n_sat, gnss_refine_result *out_dev, void *stream)
+{
+  if (!signal_dev || !codes_dev || !code_offsets_dev || !dopplers_dev || !out_dev) { set_error("gnss_refine_dev: null argument"); return ARM_MATH_ARGUMENT_ERROR; }
+  // the reference wipes into static float iw[1023 * 4], qw[1023 * 4] (:392): longer windows overrun them there, refused here
+  if (size < (uint32_t)kRefineOffs || size > (uint32_t)kRefineMaxSize) {
+    set_error("gnss_refine_dev: size %u outside %d..%d (the reference's static buffers hold 1023 * 4 samples)", size, kRefineOffs, kRefineMaxSize);
+    return ARM_MATH_ARGUMENT_ERROR;
+  }
+  if (!(sample_rate_hz > 0.0)) { set_error("gnss_refine_dev: sample rate must be positive"); return ARM_MATH_ARGUMENT_ERROR; }
+  if (n_sat == 0) return ARM_MATH_SUCCESS;
+  int dev = -1;
+  if (!hip_ok(hipGetDevice(&dev), "hipGetDevice")) return ARM_MATH_ARGUMENT_ERROR;
+  const size_t lds = refine_lds_bytes((int)size);
+  static std::atomic<bool> done[16];
+  if (!hip_ok(lds_attr_once(gnss_refine_kernel, refine_lds_bytes(kRefineMaxSize), done, dev), "gnss_refine_kernel attribute")) return ARM_MATH_ARGUMENT_ERROR;
+  note_kernel("gnss_refine_kernel", false);
+  gnss_refine_kernel<<<n_sat, 256, lds, (hipStream_t)stream>>>(reinterpret_cast<const float2 *>(signal_dev), (int)signal_stride, codes_dev, (int)size,
+                                                             code_offsets_dev, dopplers_dev, sample_rate_hz, out_dev);
+  return hip_ok(hipGetLastError(), "gnss_refine_kernel") ? ARM_MATH_SUCCESS : ARM_MATH_ARGUMENT_ERROR;
+}
+
 arm_status gnss_find_top2_peaks_dev(const float *data_dev, int32_t is_complex, int32_t data_size, int32_t pk_sep, uint32_t batch,
                                     gnss_top2 *peaks_dev, void *stream)
 {
@@ -1489,6 +1646,67 @@ void rotate_fwd(int array[], int size, int offset)
       gnss_rotate_fwd_dev((const int32_t *)a.p, (int32_t *)b.p, (uint32_t)size, offset, nullptr) != ARM_MATH_SUCCESS ||
       !hip_ok(hipMemcpy(array, b.p, (size_t)size * sizeof(int32_t), hipMemcpyDeviceToHost), "hipMemcpy(D2H)"))
     die("rotate_fwd");
+}
+
+// CMSIS/CMSIS.cpp:362-434, the harness's own name and argument list (a C++ function there; exported with C linkage here)
+double recover_prn_phase_deg_with_doppler(const float32_t *iandq, int SIZE, const int prn_a[], int code_offset, double doppler_a_hz,
+                                          double sampe_rate_hz, int *best_offset_out, float *doppler_out, float *pwr)
+{
+  if (!iandq || !prn_a || !best_offset_out || !doppler_out || !pwr) { set_error("recover_prn_phase_deg_with_doppler: null argument"); die("recover_prn_phase_deg_with_doppler"); }
+  const size_t n = (size_t)(SIZE > 0 ? SIZE : 0);
+  DevBuf sig(n * sizeof(float2)), code(n * sizeof(int32_t)), par(sizeof(double) + sizeof(int32_t) * 2), res(sizeof(gnss_refine_result));
+  struct { double dop; int32_t off; int32_t pad; } h = {doppler_a_hz, code_offset, 0};
+  gnss_refine_result r;
+  if (!sig.p || !code.p || !par.p || !res.p || !hip_ok(hipMemcpy(sig.p, iandq, n * sizeof(float2), hipMemcpyHostToDevice), "hipMemcpy(H2D)") ||
+      !hip_ok(hipMemcpy(code.p, prn_a, n * sizeof(int32_t), hipMemcpyHostToDevice), "hipMemcpy(H2D)") ||
+      !hip_ok(hipMemcpy(par.p, &h, sizeof h, hipMemcpyHostToDevice), "hipMemcpy(H2D)") ||
+      gnss_refine_dev((const float *)sig.p, 0, (uint32_t)n, (const int32_t *)code.p, (const int32_t *)((char *)par.p + 8), (const double *)par.p,
+                      sampe_rate_hz, 1, (gnss_refine_result *)res.p, nullptr) != ARM_MATH_SUCCESS ||
+      !hip_ok(hipMemcpy(&r, res.p, sizeof r, hipMemcpyDeviceToHost), "hipMemcpy(D2H)"))
+    die("recover_prn_phase_deg_with_doppler");
+  *doppler_out = r.doppler;
+  *best_offset_out = r.best_off;
+  *pwr = r.pwr;
+  return r.phase_deg;
+}
+
+// The step between the acquisition record and carr_phase (Include/msb_funcs.h:30, cycles): for every satellite of `meas` the
+// fine search above around (code phase, Doppler) of the record on the first `size` samples of `signal` (host pointer),
+// code = getCode(size / spc, spc, prn); carr_phase = phase_deg / 360.  details (optional) receives the search results.
+int gnss_meas_refine(const float32_t *signal, uint32_t size, int32_t spc, double sample_rate_hz, int32_t fft_len, bb_meas_t *meas,
+                     gnss_refine_result *details)
+{
+  if (!signal || !meas || spc < 1 || fft_len <= 0 || meas->num_sat < 0 || meas->num_sat > 20 || size % (uint32_t)spc) {
+    set_error("gnss_meas_refine: bad argument");
+    return -1;
+  }
+  const int ns = meas->num_sat;
+  if (ns == 0) return 0;
+  DevBuf sig((size_t)size * sizeof(float2)), codes((size_t)ns * size * sizeof(int32_t)), offs(ns * sizeof(int32_t)), dops(ns * sizeof(double)),
+      res(ns * sizeof(gnss_refine_result));
+  if (!sig.p || !codes.p || !offs.p || !dops.p || !res.p) return -1;
+  int32_t h_off[20];
+  double h_dop[20];
+  for (int k = 0; k < ns; k++) {
+    const bb_meas_sat_t &s = meas->sats[k];
+    h_off[k] = (int32_t)lround((double)s.code_phase * (double)fft_len) % (int32_t)size;   // code_phase [ms] = samples / fft_len (gnss_acq_to_meas)
+    if (h_off[k] < 0) h_off[k] += (int32_t)size;
+    h_dop[k] = (double)s.doppler;
+    if (gnss_get_code_dev((int32_t)(size / (uint32_t)spc), spc, (int32_t)s.prn, (int32_t *)codes.p + (size_t)k * size) != ARM_MATH_SUCCESS) return -1;
+  }
+  gnss_refine_result h_res[20];
+  if (!hip_ok(hipMemcpy(sig.p, signal, (size_t)size * sizeof(float2), hipMemcpyHostToDevice), "hipMemcpy(H2D)") ||
+      !hip_ok(hipMemcpy(offs.p, h_off, ns * sizeof(int32_t), hipMemcpyHostToDevice), "hipMemcpy(H2D)") ||
+      !hip_ok(hipMemcpy(dops.p, h_dop, ns * sizeof(double), hipMemcpyHostToDevice), "hipMemcpy(H2D)") ||
+      gnss_refine_dev((const float *)sig.p, 0, size, (const int32_t *)codes.p, (const int32_t *)offs.p, (const double *)dops.p, sample_rate_hz, (uint32_t)ns,
+                      (gnss_refine_result *)res.p, nullptr) != ARM_MATH_SUCCESS ||
+      !hip_ok(hipMemcpy(h_res, res.p, ns * sizeof(gnss_refine_result), hipMemcpyDeviceToHost), "hipMemcpy(D2H)"))
+    return -1;
+  for (int k = 0; k < ns; k++) {
+    meas->sats[k].carr_phase = (float)(h_res[k].phase_deg / 360.0);
+    if (details) details[k] = h_res[k];
+  }
+  return ns;
 }
 
 static int top2_host(const float *data, int is_complex, int data_size, int pk_sep, top2_pks *peaks, FILE *fp_out)

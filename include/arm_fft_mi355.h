@@ -391,6 +391,25 @@ arm_status gnss_make_replica_dev(const int32_t *code_dev, uint32_t size, float32
                                  void *stream);
 arm_status gnss_rotate_fwd_dev(const int32_t *in_dev, int32_t *out_dev, uint32_t size, int32_t offset, void *stream);
 
+/* Fine search around an acquired cell: recover_prn_phase_deg_with_doppler (CMSIS/CMSIS.cpp:362-434).  For f = -1, 0, +1 Hz the
+ * millisecond is wiped at doppler + f with the reference's FLOAT recursive phasor, correlated against the code at the 21
+ * offsets within +-10 samples of code_offset (wrapping around the code period) and the largest |correlation| kept, the
+ * first among equals in the reference's visiting order.  One result per satellite:
+ *   phase_deg = atan2(im, re) * (180.0f / 3.14159265358979f), best_off = the offset, doppler = the winning f, pwr = |sum|.
+ * signal_dev + k * signal_stride (complex samples; stride 0: all satellites search the same `size` samples), codes_dev =
+ * n_sat x size ints (+1 / -1), size <= 1023 * 4 (the reference's static buffers, :392).  Asynchronous on `stream`, no allocation.
+ * Parity unpinned by the reference (the harness cannot be compiled here, it holds no vector): oracle/gnss_oracle.c restates it. */
+typedef struct {
+  double phase_deg;
+  float32_t pwr;
+  float32_t doppler;
+  int32_t best_off;
+  int32_t reserved;
+} gnss_refine_result;
+arm_status gnss_refine_dev(const float32_t *signal_dev, uint32_t signal_stride, uint32_t size, const int32_t *codes_dev,
+                           const int32_t *code_offsets_dev, const double *dopplers_dev, double sample_rate_hz, uint32_t n_sat,
+                           gnss_refine_result *out_dev, void *stream);
+
 /* The reference's own names for those helpers (Include/gnss_codes.h:62-126), host pointers; `c32` arrays are passed
  * as interleaved float32_t I/Q (Include/cplx_types.h:9: struct { float r, i; }, same memory).  Each stages its
  * arguments to the current device, runs the kernel above and copies the result back.
@@ -426,6 +445,10 @@ int find_top2_peaks_real(const float32_t *data, int data_size, int pk_sep, top2_
 double compute_snr_cplx(float32_t *convol, int cov_size, double peak, int peak_loc);
 double compute_snr_real(float32_t *convol, int cov_size, double peak, int peak_loc);
 double InterpolateCodePhase(uint32_t index, double earlyPower, double promptPower, double latePower);
+/* CMSIS/CMSIS.cpp:362-434 under the harness's own name and argument list (iandq = c32[SIZE] as interleaved floats); aborts with a
+ * message when the GPU cannot run it or SIZE is outside 21 .. 4092 */
+double recover_prn_phase_deg_with_doppler(const float32_t *iandq, int SIZE, const int prn_a[], int code_offset, double doppler_a_hz,
+                                          double sampe_rate_hz, int *best_offset_out, float *doppler_out, float *pwr);
 
 /* ---- codes of any length through caller-supplied replicas ----
  * The fork correlates L5 / E5a codes (10230 chips at 10.23 Msps) by resampling signal and replica
@@ -538,6 +561,12 @@ void read_bb_msb(uint8_t *bin_buff, int bin_size, bb_meas_t *measurements);
  * appended, -1 on a bad argument. */
 int gnss_acq_to_meas(const gnss_acq_result *best, int n, const float32_t *dopplers_hz, int n_dop, int fft_len, float ratio_min,
                      float cno_offset_db, uint16_t constellation, bb_meas_t *meas);
+/* carr_phase (msb_funcs.h:30, cycles) of every satellite in meas: the fine search above on the first `size` samples of `signal`
+ * (HOST pointer, interleaved I/Q; size a multiple of spc, <= 4092) around the record's code phase (code_phase * fft_len samples)
+ * and Doppler, code = getCode(size / spc, spc, prn); carr_phase = phase_deg / 360.  details (optional, num_sat entries) receives
+ * the searches' results.  Returns the number of satellites refined, -1 on a bad argument or when the GPU cannot run. */
+int gnss_meas_refine(const float32_t *signal, uint32_t size, int32_t spc, double sample_rate_hz, int32_t fft_len, bb_meas_t *meas,
+                     gnss_refine_result *details);
 
 /* ---- library services (no counterpart in the reference) ---- */
 /* Select the GPU used by the calling thread's host-pointer entry points and build nothing else;

@@ -102,6 +102,70 @@ int orc_rotate_fwd(int *array, int size, int offset)
   return 0;
 }
 
+/* recover_prn_phase_deg_with_doppler (CMSIS/CMSIS.cpp:362-434), statement by statement: float recursive phasor
+ * without renormalisation, float wipe products, double correlation sums in index order, the window and its wrap
+ * flags as floats, strict ">" for the running best.  PI there is the FLOAT literal (Include/gnss_codes.h:33),
+ * R2D = (180.0f / 3.14159265358979f) (CMSIS.cpp:26).  SIZE <= 4092 (static float iw[1023 * 4]).
+ * Parity unpinned by the reference: the harness is Windows-only C++ and holds no vector. */
+double orc_recover_prn_phase(const orc_c32 *iandq, int SIZE, const int *prn_a, int code_offset, double doppler_a_hz,
+                             double sample_rate_hz, int *best_offset_out, float *doppler_out, float *pwr)
+{
+  const double REF_PI = (double)3.14159265358979f;
+  const float R2D = (180.0f / 3.14159265358979f);
+  double best_pow = -1.0, best_re = 0.0, best_im = 0.0, best_doppler = 0.0;
+  int best_off = 0;
+  if (SIZE <= 0 || SIZE > 1023 * 4) return 0.0 / 0.0;
+  float code_search_span = 10;
+  float code_low = code_offset - code_search_span;
+  float code_high = code_offset + code_search_span;
+  unsigned char wrap = 0;
+  if (code_low < 0) { code_low += SIZE; wrap = 1; }
+  if (code_high > SIZE) { code_high -= SIZE; wrap = 1; }
+  float f_search_step_hz = 1.0;
+  float f_search_span_hz = 1;
+  float *iw = (float *)malloc(sizeof(float) * (size_t)SIZE), *qw = (float *)malloc(sizeof(float) * (size_t)SIZE);
+  for (float f = -f_search_span_hz; f <= +f_search_span_hz + 1e-3f; f += f_search_step_hz) {
+    double dtheta = 2.0 * REF_PI * (doppler_a_hz + f) / (double)sample_rate_hz;
+    const float c_inc = (float)cos(dtheta);
+    const float s_inc = (float)sin(dtheta);
+    float pc = 1.0f, ps = 0.0f;
+    for (int n = 0; n < SIZE; ++n) {
+      float I = iandq[n].r, Q = iandq[n].i;
+      iw[n] = +I * pc + Q * ps;
+      qw[n] = -I * ps + Q * pc;
+      float npc = pc * c_inc - ps * s_inc;
+      float nps = pc * s_inc + ps * c_inc;
+      pc = npc;
+      ps = nps;
+    }
+    for (int off = 0; off < SIZE; ++off) {
+      if (wrap == 0 && (off < code_low || off > code_high)) continue;
+      if (wrap == 1 && (off > code_high && off < code_low)) continue;
+      double re = 0.0, im = 0.0;
+      for (int n = 0; n < SIZE; ++n) {
+        int idx = n - off;
+        if (idx < 0) idx += SIZE;
+        re += iw[n] * prn_a[idx];
+        im += qw[n] * prn_a[idx];
+      }
+      double p = sqrt(re * re + im * im);
+      if (p > best_pow) {
+        best_pow = p;
+        best_doppler = (double)f;
+        best_re = re;
+        best_im = im;
+        best_off = off;
+      }
+    }
+  }
+  free(iw);
+  free(qw);
+  *doppler_out = (float)best_doppler;
+  *best_offset_out = best_off;
+  *pwr = (float)best_pow;
+  return atan2(best_im, best_re) * R2D;
+}
+
 /* synth_gps_prn (gnss_codes.c:1066-1071) */
 void orc_synth_gps_prn(int prn, float doppler, int size, orc_c32 *replica, int spc)
 {

@@ -228,3 +228,51 @@ def test_l5_generator_properties_of_the_reference_as_written():
     assert np.array_equal(np.roll(a, -5), b) or np.array_equal(np.roll(a, 5), b)
     assert H.oracle().orc_l5_generate_I(0, a.ctypes.data_as(ctypes.c_void_p), 8) == -1
     assert H.oracle().orc_l5_generate_I(38, a.ctypes.data_as(ctypes.c_void_p), 8) == -1
+
+
+# ---- fine search (recover_prn_phase_deg_with_doppler, CMSIS/CMSIS.cpp:362-434): parity unpinned by the reference ----
+def orc_refine(sig, code, code_offset, doppler, fs):
+    L = H.oracle()
+    L.orc_recover_prn_phase.restype = ctypes.c_double
+    L.orc_recover_prn_phase.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_double,
+                                        ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
+    off, dop, pwr = ctypes.c_int(), ctypes.c_float(), ctypes.c_float()
+    sig = np.ascontiguousarray(sig, np.float32)
+    code = np.ascontiguousarray(code, np.int32)
+    ph = L.orc_recover_prn_phase(sig.ctypes.data_as(ctypes.c_void_p), len(code), code.ctypes.data_as(ctypes.c_void_p), code_offset, doppler, fs,
+                                 ctypes.byref(off), ctypes.byref(dop), ctypes.byref(pwr))
+    return ph, off.value, dop.value, pwr.value
+
+
+def refine_scene(prn, delay, doppler, phase_deg, spc=4, sigma=0.5, seed=5):
+    """one millisecond of code(prn) delayed by `delay` samples on a carrier at `doppler` with initial phase phase_deg + noise"""
+    code = H.ca_code(prn, spc)
+    n = np.arange(code.size)
+    fs = 1.023e6 * spc
+    x = np.roll(code, delay) * np.exp(1j * (np.deg2rad(phase_deg) + 2 * np.pi * doppler * n / fs))
+    g = H.rng(seed)
+    x = x + sigma * (g.standard_normal(n.size) + 1j * g.standard_normal(n.size))
+    return np.stack([x.real, x.imag], -1).astype(np.float32), code, fs
+
+
+@pytest.mark.parametrize("delay,start,doppler,phase", [(1033, 1030, 1500.0, 40.0), (3, 1, -2250.0, -120.0), (4088, 4090, 750.0, 10.0),
+                                                       (4082, 4082, 0.0, 179.0), (0, 9, 4750.0, -5.0), (2047, 2040, -4250.0, 90.0)])
+def test_fine_search_recovers_delay_and_phase(delay, start, doppler, phase):
+    sig, code, fs = refine_scene(7, delay, doppler, phase)
+    ph, off, f, pwr = orc_refine(sig, code, start, doppler, fs)
+    assert off == delay and f in (-1.0, 0.0, 1.0)
+    # the carrier phase at sample 0 (the wipe-off removes the Doppler), to the noise: 4092 samples at sigma 0.5
+    assert abs((ph - phase + 180.0) % 360.0 - 180.0) < 2.0
+    assert abs(pwr - code.size) < 0.05 * code.size
+
+
+def test_fine_search_window_edges():
+    """:376-380, :408-409: 21 offsets around the start, wrapping past either end of the period; start + 10 == SIZE does NOT wrap
+    (and then offset 0 is not searched)"""
+    sig, code, fs = refine_scene(9, 0, 1000.0, 30.0, sigma=0.0)
+    n = code.size
+    assert orc_refine(sig, code, n - 10, 1000.0, fs)[1] != 0          # window [n-20, n]: offset n is never visited, 0 is outside
+    assert orc_refine(sig, code, n - 9, 1000.0, fs)[1] == 0           # code_high = n + 1 > n: wraps, 0 is inside
+    assert orc_refine(sig, code, 5, 1000.0, fs)[1] == 0
+    sig2, _, _ = refine_scene(9, n - 3, 1000.0, 30.0, sigma=0.0)
+    assert orc_refine(sig2, code, 4, 1000.0, fs)[1] == n - 3          # code_low < 0: wraps the other way
