@@ -19,7 +19,7 @@ def test_header_and_library_agree():
     hdr = open(os.path.join(H.ROOT, "include", "arm_fft_mi355.h")).read()
     declared = set(re.findall(r"\b((?:arm_(?:cfft|rfft_fast|rfft|fft_mi355)|gnss|up_sample|iq_resamp|write_bb|read_bb)_[A-Za-z0-9_]+)\s*\(", hdr))
     # the reference's own GNSS helper names (Include/gnss_codes.h:62-126) carry no common prefix
-    declared |= set(re.findall(r"\b(getCode|synth_gps_prn|mix_prn|make_replica|rotate_fwd|find_top2_peaks_cplx|find_top2_peaks_real|compute_snr_cplx|compute_snr_real|InterpolateCodePhase)\s*\(", hdr))
+    declared |= set(re.findall(r"\b(getCode|synth_gps_prn|mix_prn|make_replica|rotate_fwd|recover_prn_phase_deg_with_doppler|find_top2_peaks_cplx|find_top2_peaks_real|compute_snr_cplx|compute_snr_real|InterpolateCodePhase)\s*\(", hdr))
     assert declared, "no declarations found"
     missing = [s for s in sorted(declared) if not hasattr(lib, s)]
     assert not missing, "declared but not exported: %s" % missing
