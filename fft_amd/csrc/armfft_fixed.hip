@@ -12,6 +12,7 @@
 // arm_bitreversal_16/_32 (arm_bitreversal2.c:84-148, plain bit reversal for the fixed tables) is
 // folded into the final, coalesced store.
 #include <atomic>
+#include <type_traits>
 
 #include "armfft_internal.h"
 
@@ -1039,29 +1040,42 @@ hipError_t launch_cfft_q31(int logn, int32_t *data, const int32_t *tw, uint32_t 
 //   inverse:  split_rifft while loading (reads L+1 complex) -> inverse cfft -> saturating << 1 on store
 // A/B = realCoefA/B tables (8192 scalars, 4096 pairs), mod = twidCoefRModifier.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ int32_t mult_r(int32_t x, int32_t y) { return (int32_t)(((long long)x * y + 0x80000000LL) >> 32); }
-__device__ __forceinline__ int32_t macc_r(int32_t a, int32_t x, int32_t y)
+// x * y + c on 64 bits (wrapping) as ONE v_mad_i64_i32.  Written out: with a coefficient that takes part in four products
+// the compiler keeps its sign extension in a register pair and multiplies 64 x 64 bits -- three quarter-rate instructions
+// and two additions per product instead of one (measured in the split of 512 real q31 points: 85 v_mul_lo_u32 and
+// 40 v_mad_u64_u32 next to the 88 v_mad_i64_i32 it did find).
+__device__ __forceinline__ long long mad64(int32_t x, int32_t y, long long c)
 {
-  return (int32_t)((long long)(((unsigned long long)(long long)a << 32) + (unsigned long long)((long long)x * y) + 0x80000000ULL) >> 32);
+  long long r;
+  unsigned long long carry;
+  asm("v_mad_i64_i32 %0, %1, %2, %3, %4" : "=&v"(r), "=s"(carry) : "v"(x), "v"(y), "v"(c));
+  return r;
 }
+__device__ __forceinline__ long long hi_half(int32_t a) { return (long long)(((unsigned long long)(uint32_t)a << 32) | 0x80000000ULL); }  // a.5 in 32.32
+__device__ __forceinline__ int32_t mult_r(int32_t x, int32_t y) { return (int32_t)(mad64(x, y, 0x80000000LL) >> 32); }
+__device__ __forceinline__ int32_t macc_r(int32_t a, int32_t x, int32_t y) { return (int32_t)(mad64(x, y, hi_half(a)) >> 32); }
 __device__ __forceinline__ int32_t msub_r(int32_t a, int32_t x, int32_t y)
 {
-  return (int32_t)((long long)(((unsigned long long)(long long)a << 32) - (unsigned long long)((long long)x * y) + 0x80000000ULL) >> 32);
+  return (int32_t)((long long)((unsigned long long)hi_half(a) - (unsigned long long)mad64(x, y, 0)) >> 32);
 }
 
 // forward split of bin i (1 <= i < L) from s1 = X[i], s2 = X[L-i]; returns the word for position i;
 // the mirrored position 2L - i holds (re, -im)
+// (q15: the four products of a sum are two v_dot2_i32_i16; a product that is SUBTRACTED uses the complement of its
+// coefficient, x * ~y = -x*y - x, and x goes in through the accumulator: everything is arithmetic modulo 2^32 like the
+// reference's 32-bit sums, and ~y exists for every y, which -y does not)
 __device__ __forceinline__ Q15::cpx split_fwd(Q15::cpx s1, Q15::cpx s2, Q15::cpx a, Q15::cpx b)
 {
-  int32_t outR = s1.re * a.re;
-  outR = wsub(outR, s1.im * a.im);
-  outR = wadd(outR, s2.re * b.re);
-  outR = wadd(outR, s2.im * b.im) >> 16;
-  int32_t outI = s2.re * b.im;
-  outI = wsub(outI, s2.im * b.re);
-  outI = wadd(outI, s1.im * a.re);
-  outI = wadd(outI, s1.re * a.im);
-  return Q15::cpx{(int16_t)outR, (int16_t)(outI >> 16)};
+  const s16x2 v1 = to_v(s1), v2 = to_v(s2), va = to_v(a), vb = to_v(b);
+  const s16x2 a_n = va ^ s16x2{0, -1};                 // {a.re, ~a.im}
+  const s16x2 b_n = swap_ri(vb ^ s16x2{-1, 0});        // {b.im, ~b.re}
+  // outR = s1.re a.re - s1.im a.im + s2.re b.re + s2.im b.im
+  int32_t outR = __builtin_amdgcn_sdot2(v2, vb, (int)s1.im, false);
+  outR = __builtin_amdgcn_sdot2(v1, a_n, outR, false);
+  // outI = s2.re b.im - s2.im b.re + s1.im a.re + s1.re a.im
+  int32_t outI = __builtin_amdgcn_sdot2(v1, swap_ri(va), (int)s2.im, false);
+  outI = __builtin_amdgcn_sdot2(v2, b_n, outI, false);
+  return Q15::cpx{(int16_t)(outR >> 16), (int16_t)(outI >> 16)};
 }
 __device__ __forceinline__ Q31::cpx split_fwd(Q31::cpx s1, Q31::cpx s2, Q31::cpx a, Q31::cpx b)
 {
@@ -1092,15 +1106,14 @@ __device__ __forceinline__ Q31::cpx dc_word(Q31::cpx x, bool nyq)
 // inverse split of point i (0 <= i < L) from s1 = X[i], s2 = X[L-i]
 __device__ __forceinline__ Q15::cpx split_inv(Q15::cpx s1, Q15::cpx s2, Q15::cpx a, Q15::cpx b)
 {
-  int32_t outR = s2.re * b.re;
-  outR = wsub(outR, s2.im * b.im);
-  outR = wadd(outR, s1.re * a.re);
-  outR = wadd(outR, s1.im * a.im) >> 16;
-  int32_t outI = s1.im * a.re;
-  outI = wsub(outI, s1.re * a.im);
-  outI = wsub(outI, s2.re * b.im);
-  outI = wsub(outI, s2.im * b.re);
-  return Q15::cpx{(int16_t)outR, (int16_t)(outI >> 16)};
+  const s16x2 v1 = to_v(s1), v2 = to_v(s2), va = to_v(a), vb = to_v(b);
+  // outR = s2.re b.re - s2.im b.im + s1.re a.re + s1.im a.im
+  int32_t outR = __builtin_amdgcn_sdot2(v2, vb ^ s16x2{0, -1}, (int)s2.im, false);
+  outR = __builtin_amdgcn_sdot2(v1, va, outR, false);
+  // outI = s1.im a.re - s1.re a.im - s2.re b.im - s2.im b.re
+  int32_t outI = __builtin_amdgcn_sdot2(v1, swap_ri(va) ^ s16x2{-1, 0}, (int)s1.re + (int)s2.re + (int)s2.im, false);   // {~a.im, a.re}
+  outI = __builtin_amdgcn_sdot2(v2, swap_ri(vb) ^ s16x2{-1, -1}, outI, false);                                 // {~b.im, ~b.re}
+  return Q15::cpx{(int16_t)(outR >> 16), (int16_t)(outI >> 16)};
 }
 __device__ __forceinline__ Q31::cpx split_inv(Q31::cpx s1, Q31::cpx s2, Q31::cpx a, Q31::cpx b)
 {
@@ -1126,8 +1139,11 @@ __device__ __forceinline__ Q31::cpx sat_shl1(Q31::cpx v) { return Q31::cpx{sat_d
 
 // LOGN = log2(L).  Forward: in = L words per transform, out = 2L words.  Inverse: in = L + 1 words per
 // transform (stride L + 1), out = L words.
+#ifndef ARMFFT_RFFT_MINW
+#define ARMFFT_RFFT_MINW 4
+#endif
 template <class Q, int LOGN, bool INV>
-__global__ __launch_bounds__(FixedPlan<LOGN>::T, 4) void rfft_fixed_kernel(const typename Q::word *__restrict__ in,
+__global__ __launch_bounds__(FixedPlan<LOGN>::T, ARMFFT_RFFT_MINW) void rfft_fixed_kernel(const typename Q::word *__restrict__ in,
                                                                           typename Q::word *__restrict__ out,
                                                                           const typename Q::tword *__restrict__ tw,
                                                                           const typename Q::tword *__restrict__ coefA,
@@ -1154,7 +1170,10 @@ __global__ __launch_bounds__(FixedPlan<LOGN>::T, 4) void rfft_fixed_kernel(const
   // loop below): fetched here, behind the data loads
   constexpr int SPER = (sizeof(word) == 8 || LOGN <= 9) ? 16 / sizeof(word) : 1, SITER = PL::ELEMS / SPER / PL::T;
   static_assert(SITER * SPER == 16 && SITER * SPER * PL::T == PL::ELEMS, "16 bins per thread");
-  typename Q::tword ca[INV ? 1 : 16], cb[INV ? 1 : 16];
+  // (step `it` covers bins ((tid + it T) SPER mod L) + k: T SPER bins per step, so the steps share L / (T SPER) sets)
+  constexpr int NSETS = (L > PL::T * SPER) ? L / (PL::T * SPER) : 1, NC = NSETS * SPER;
+  static_assert(NC <= 16, "coefficient sets");
+  typename Q::tword ca[INV ? 1 : NC], cb[INV ? 1 : NC];
   // ---- load ----
   if (!INV) {
     const word *__restrict__ src = in + (size_t)tr0 * L;
@@ -1168,12 +1187,12 @@ __global__ __launch_bounds__(FixedPlan<LOGN>::T, 4) void rfft_fixed_kernel(const
       for (int k = 0; k < PER16; k++) lds[fpad(e + k)] = pw[k];
     }
 #pragma unroll
-    for (int it = 0; it < SITER; it++) {
+    for (int set = 0; set < NSETS; set++) {
 #pragma unroll
       for (int k = 0; k < SPER; k++) {
-        const int i = (((tid + it * PL::T) * SPER) & (L - 1)) + k;
-        ca[INV ? 0 : it * SPER + k] = coefA[i * mod];
-        cb[INV ? 0 : it * SPER + k] = coefB[i * mod];
+        const int i = (((tid + set * PL::T) * SPER) & (L - 1)) + k;
+        ca[INV ? 0 : set * SPER + k] = coefA[i * mod];
+        cb[INV ? 0 : set * SPER + k] = coefB[i * mod];
       }
     }
   } else {
@@ -1224,37 +1243,87 @@ __global__ __launch_bounds__(FixedPlan<LOGN>::T, 4) void rfft_fixed_kernel(const
   // ---- store ----
   if (!INV) {
     word *__restrict__ dst = out + (size_t)tr0 * (2 * L);
-    // bin i is split once and written twice: position i and, conjugated, the mirrored position
-    // 2L - i (a descending but still contiguous run across the lanes); i = 0 yields the DC word
-    // and the Nyquist word at position L
-    // a thread takes 16 bytes' worth of consecutive bins: one 16-byte store for the direct half,
-    // word stores for the mirrored half (its run is offset by one word from 16-byte alignment)
-    // (measured: pays for q31 and for q15 up to 1024 real points; larger q15 transforms lose 10 % to
-    // the LDS conflicts of four bit-reversed reads per lane and keep one bin per lane)
-    constexpr int PER16 = SPER;
+    // A thread splits SPER consecutive bins i0 .. i0+SPER-1 (16 bytes' worth) and stores them at position i0.  Their
+    // conjugates belong at 2L-i0-SPER+1 .. 2L-i0, one word off 16-byte alignment, so the thread stores the ALIGNED
+    // chunk [2L-i0-SPER, 2L-i0) instead: its own bins i0+1 .. i0+SPER-1 and bin i0+SPER, the first bin of the next lane
+    // (wave shift; lane 63 takes lane 0's first bin of the next step; at the end of a transform it is the Nyquist word).
+    // Stored straight from the lanes that split them, the mirrored words of a store instruction lay 16 bytes apart and
+    // every 128-byte line of that half was written by partial stores of several instructions.
+    auto from_next_lane = [&](word w, word lane0_next) -> word {
+      constexpr int NW32 = sizeof(word) / 4;
+      int *pw = reinterpret_cast<int *>(&w), *pn = reinterpret_cast<int *>(&lane0_next);
+      word r;
+      int *pr = reinterpret_cast<int *>(&r);
 #pragma unroll
-    for (int it = 0; it < SITER; it++) {
-      const int v = tid + it * PL::T;
-      const int e = v * PER16, t = e >> LOGN, i0 = e & (L - 1);
-      if ((uint32_t)t >= nvt) continue;
-      word *__restrict__ d = dst + (size_t)t * (2 * L);
-      uint4 raw;
-      word *pw = reinterpret_cast<word *>(&raw);
-#pragma unroll
-      for (int k = 0; k < PER16; k++) {
-        const int i = i0 + k;
-        if (i == 0) {
-          const cpx x0 = X(t, 0);
-          pw[k] = Q::pack(dc_word(x0, false));
-          d[L] = Q::pack(dc_word(x0, true));
-        } else {
-          const cpx o = split_fwd(X(t, i), X(t, L - i), Q::unpack(ca[INV ? 0 : it * SPER + k]), Q::unpack(cb[INV ? 0 : it * SPER + k]));
-          pw[k] = Q::pack(o);
-          d[2 * L - i] = Q::pack(mirror(o));
-        }
+      for (int h = 0; h < NW32; h++) {
+        const int sh = __builtin_amdgcn_update_dpp(0, pw[h], 0x130, 0xF, 0xF, false);   // wave_shl:1 -- lane l reads lane l+1
+        const int first = __builtin_amdgcn_readfirstlane(pn[h]);   // (outside the select: every lane takes part)
+        pr[h] = (tid & 63) == 63 ? first : sh;
       }
-      if constexpr (PER16 > 1) *reinterpret_cast<uint4 *>(d + i0) = raw;
-      else d[i0] = pw[0];
+      return r;
+    };
+    // the SPER bins of step `it` into w[]
+    auto split_step = [&](int it, word *w) {
+      const int e = (tid + it * PL::T) * SPER, t = e >> LOGN, i0 = e & (L - 1);
+#pragma unroll
+      for (int k = 0; k < SPER; k++) {
+        const int i = i0 + k, ci = INV ? 0 : (it % NSETS) * SPER + k;
+        const cpx xi = X(t, i);
+        const cpx o = split_fwd(xi, X(t, (L - i) & (L - 1)), Q::unpack(ca[ci]), Q::unpack(cb[ci]));
+        w[k] = Q::pack(i == 0 ? xi : o);                        // bin 0: the raw X[0], for the DC and Nyquist words
+      }
+    };
+    // step `it`: its bins w[] at position i0, the aligned mirrored chunk with `nxt` = bin i0 + SPER
+    auto store_step = [&](int it, const word *w, word nxt) {
+      const int e = (tid + it * PL::T) * SPER, t = e >> LOGN, i0 = e & (L - 1);
+      if ((uint32_t)t >= nvt) return;
+      word *__restrict__ d = dst + (size_t)t * (2 * L);
+      cpx nx = mirror(Q::unpack(nxt));
+      if (i0 + SPER == L) nx = dc_word(X(t, 0), true);
+      uint4 raw, rawm;
+      word *pw = reinterpret_cast<word *>(&raw), *pm = reinterpret_cast<word *>(&rawm);
+      pm[0] = Q::pack(nx);
+#pragma unroll
+      for (int k = 0; k < SPER; k++) {
+        const cpx c = Q::unpack(w[k]);
+        pw[k] = (i0 + k == 0) ? Q::pack(dc_word(c, false)) : w[k];
+        if (k > 0) pm[SPER - k] = Q::pack(mirror(c));
+      }
+      if constexpr (PL::T != 64) {
+        // several waves (2048 complex points and up, natural-order output only -- the bit-reversed order takes the direct
+        // form there): the next lane of lane 63 is another wave's; every lane stores its own conjugates
+        if (i0 == 0) d[L] = Q::pack(dc_word(X(t, 0), true));
+#pragma unroll
+        for (int k = 0; k < SPER; k++)
+          if (i0 + k != 0) d[2 * L - i0 - k] = Q::pack(mirror(Q::unpack(w[k])));
+        if constexpr (SPER > 1) *reinterpret_cast<uint4 *>(d + i0) = raw;
+        else d[i0] = pw[0];
+      } else if constexpr (SPER > 1) {
+        *reinterpret_cast<uint4 *>(d + i0) = raw;
+        *reinterpret_cast<uint4 *>(d + 2 * L - i0 - SPER) = rawm;
+      } else {
+        d[i0] = pw[0];
+        d[2 * L - i0 - 1] = pm[0];
+      }
+    };
+    if constexpr (sizeof(word) == 4) {
+      // q15: every step split first (16 registers), then the stores
+      word ow[16];
+#pragma unroll
+      for (int it = 0; it < SITER; it++) split_step(it, ow + it * SPER);
+#pragma unroll
+      for (int it = 0; it < SITER; it++)
+        store_step(it, ow + it * SPER, from_next_lane(ow[it * SPER], ow[(it + 1 < SITER ? it + 1 : it) * SPER]));
+    } else {
+      // q31 (the same in 32 registers spills): step `it` is split, then step it-1, which waited for this step's first bin, is stored
+      word cur[SPER], prv[SPER];
+#pragma unroll
+      for (int it = 0; it <= SITER; it++) {
+        if (it < SITER) split_step(it, cur);
+        if (it > 0) store_step(it - 1, prv, from_next_lane(prv[0], it < SITER ? cur[0] : prv[0]));
+#pragma unroll
+        for (int k = 0; k < SPER; k++) prv[k] = cur[k];
+      }
     }
   } else {
     word *__restrict__ dst = out + (size_t)tr0 * L;
@@ -1314,19 +1383,23 @@ __global__ __launch_bounds__(DirectPlan<LOGN>::WG) void rfft_fixed_direct_kernel
 #pragma unroll
     for (int c = 0; c < 16; c++) lds[direct_rc(c) * T + tid] = Q::pack(direct_out<Q, LOGN>(x[c]));
     __syncthreads();
+    // The mirrored half as whole, aligned runs of T words: bins cT+1 .. cT+T-1 (lanes 1 .. T-1) land in
+    // [2L-(c+1)T+1, 2L-cT), and the run's first word, position 2L-(c+1)T, is the mirror of bin (c+1)T -- lane 0's NEXT
+    // result (the Nyquist word after the last one).  Written per c with the lanes' own bins, the runs would start one word
+    // off the line and every line would be written by two instructions.
+    const cpx x0 = Q::unpack(lds[0]);
+    const int vmir = vout + (2 * L - 15 * T - (tid ? tid : T)) * W;   // mirror run m at + (15 - m) T words
+    word prev{};
 #pragma unroll
     for (int c = 0; c < 16; c++) {
       const int i = tid + c * T;
-      if (i == 0) {
-        const cpx x0 = Q::unpack(lds[0]);
-        DirectIo<Q>::store(Q::pack(dc_word(x0, false)), ro, vout, 0);
-        DirectIo<Q>::store(Q::pack(dc_word(x0, true)), ro, vout, L * W);
-      } else {
-        const cpx o = split_fwd(Q::unpack(lds[i]), Q::unpack(lds[L - i]), Q::unpack(ca[c]), Q::unpack(cb[c]));
-        DirectIo<Q>::store(Q::pack(o), ro, vout + tid * W, c * T * W);
-        DirectIo<Q>::store(Q::pack(mirror(o)), ro, vout + (2 * L - i) * W, 0);
-      }
+      const cpx o = split_fwd(Q::unpack(lds[i]), Q::unpack(lds[(L - i) & (L - 1)]), Q::unpack(ca[c]), Q::unpack(cb[c]));
+      const word ow = Q::pack(i == 0 ? dc_word(x0, false) : o), om = Q::pack(mirror(o));
+      DirectIo<Q>::store(ow, ro, vout + tid * W, c * T * W);
+      if (c > 0) DirectIo<Q>::store(tid ? prev : om, ro, vmir, (16 - c) * T * W);
+      prev = om;
     }
+    DirectIo<Q>::store(tid ? prev : Q::pack(dc_word(x0, true)), ro, vmir, 0);
   } else {
     const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc(const_cast<word *>(in) + (size_t)t0 * (L + 1), 0, (int)(nvalid * (L + 1) * W), 0x00020000);
     const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)t0 * L, 0, (int)(nvalid * L * W), 0x00020000);
@@ -1341,6 +1414,148 @@ __global__ __launch_bounds__(DirectPlan<LOGN>::WG) void rfft_fixed_direct_kernel
 #pragma unroll
     for (int c = 0; c < 16; c++) DirectIo<Q>::store(Q::pack(sat_shl1(direct_out<Q, LOGN>(x[c]))), ro, vout, direct_rc(c) * T * W);
   }
+}
+
+// Lane form of the fixed-point real FFT for 32 and 64 real points (L = 16 / 32 complex, bit-reversed cfft order = the
+// reference's configuration): ONE LANE PER TRANSFORM.  All stages, the bit reversal and the split run on registers with
+// compile-time indices; the twiddles and the split's coefficients have the same index in every lane, so they are scalar
+// loads.  LDS only turns the rows of a wave's 64 transforms into lane-contiguous 16-byte global accesses (a row is padded
+// by 16 bytes: the 16-byte row reads and writes of the lanes are conflict-free).  The LDS form above spends its
+// instructions on per-element index arithmetic at these sizes (1221 vector instructions per 16 points at 32 real q15
+// points); this one runs the butterflies and little else.
+template <class Q, int LOGN, bool INV>
+__global__ __launch_bounds__(64) void rfft_fixed_lane_kernel(const typename Q::word *__restrict__ in, typename Q::word *__restrict__ out,
+                                                             const typename Q::tword *__restrict__ tw,
+                                                             const typename Q::tword *__restrict__ coefA,
+                                                             const typename Q::tword *__restrict__ coefB, int mod, uint32_t batch)
+{
+  static_assert(LOGN == 4 || LOGN == 5, "16 or 32 complex points");
+  using word = typename Q::word;
+  using cpx = typename Q::cpx;
+  constexpr int L = 1 << LOGN, W = sizeof(word), PER16 = 16 / W, CPR = L / PER16;   // CPR: 16-byte chunks per row of L words
+  constexpr int ROWB = L * W + 16;
+  constexpr bool BY2 = (LOGN & 1) != 0;
+  constexpr bool WHOLE = !INV && L * W < 128;   // forward output staged as whole rows of 2L words
+  __shared__ __attribute__((aligned(16))) unsigned char stage[64 * (WHOLE ? 2 * L * W + 16 : ROWB)];
+  const int lane = threadIdx.x;
+  const uint32_t t0 = (blockIdx.x + blockIdx.y * gridDim.x) * 64u;
+  if (t0 >= batch) return;
+  const int nvalid = batch - t0 < 64u ? (int)(batch - t0) : 64;
+  // rows of L words between global memory (chunk v = lane + 64k of the wave's 64 rows) and the lanes' registers
+  auto rows_in = [&](const word *__restrict__ src, cpx *x) {
+#pragma unroll
+    for (int k = 0; k < CPR; k++) {
+      const int v = lane + 64 * k, row = v / CPR, col = v % CPR;
+      uint4 raw = make_uint4(0u, 0u, 0u, 0u);
+      if (row < nvalid) raw = reinterpret_cast<const uint4 *>(src)[v];
+      *reinterpret_cast<uint4 *>(stage + row * ROWB + col * 16) = raw;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < CPR; k++) {
+      const uint4 raw = *reinterpret_cast<const uint4 *>(stage + lane * ROWB + k * 16);
+      const word *pw = reinterpret_cast<const word *>(&raw);
+#pragma unroll
+      for (int q = 0; q < PER16; q++) x[k * PER16 + q] = Q::unpack(pw[q]);
+    }
+    __syncthreads();
+  };
+  // RW words o[] of every lane to row (lane * rows_per_transform + h) of dst, rows of RW words
+  auto rows_out = [&](word *__restrict__ dst, const word *o, auto rw, int rows_per_transform, int h) {
+    constexpr int RW = decltype(rw)::value, CP = RW / PER16, RB = RW * W + 16;
+#pragma unroll
+    for (int k = 0; k < CP; k++) {
+      uint4 raw;
+      word *pw = reinterpret_cast<word *>(&raw);
+#pragma unroll
+      for (int q = 0; q < PER16; q++) pw[q] = o[k * PER16 + q];
+      *reinterpret_cast<uint4 *>(stage + lane * RB + k * 16) = raw;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < CP; k++) {
+      const int v = lane + 64 * k, row = v / CP, col = v % CP;
+      if (row < nvalid)
+        reinterpret_cast<uint4 *>(dst)[(size_t)(row * rows_per_transform + h) * CP + col] = *reinterpret_cast<const uint4 *>(stage + row * RB + col * 16);
+    }
+    __syncthreads();
+  };
+  // the complex transform of arm_cfft_*: radix-2 pre-stage at 32 points, then stages 0 and 1 of the 16-point transforms
+  auto tws = [&](int ic) { return tw[ic]; };
+  auto transform = [&](cpx *x) {
+    if constexpr (BY2) {
+#pragma unroll
+      for (int i = 0; i < 16; i++) by2<Q, INV>(x[i], x[i + 16], Q::unpack(tw[i]));
+      pair_butterflies<Q, 4, 0, INV, 2>(x, 0, tws, tws);
+      pair_butterflies<Q, 4, 0, INV, 2>(x + 16, 0, tws, tws);
+    } else {
+      pair_butterflies<Q, 4, 0, INV, 1>(x, 0, tws, tws);
+    }
+  };
+  // bin i as arm_cfft_* leaves it: bit reversal over LOGN bits, the final << 1 of radix4by2
+  auto bin = [&](const cpx *x, int i) -> cpx {
+    const int src = (int)(__brev((unsigned)i) >> (32 - LOGN));
+    return BY2 ? shl1<Q>(x[src]) : x[src];
+  };
+
+  cpx x[L];
+  if (!INV) {
+    rows_in(in + (size_t)t0 * L, x);
+    transform(x);
+    word o[2 * L];
+    const cpx x0 = bin(x, 0);
+    o[0] = Q::pack(dc_word(x0, false));
+    o[L] = Q::pack(dc_word(x0, true));
+#pragma unroll
+    for (int i = 1; i < L; i++) {
+      const cpx c = split_fwd(bin(x, i), bin(x, L - i), Q::unpack(coefA[i * mod]), Q::unpack(coefB[i * mod]));
+      o[i] = Q::pack(c);
+      o[2 * L - i] = Q::pack(mirror(c));
+    }
+    word *__restrict__ dst = out + (size_t)t0 * (2 * L);
+    // a store instruction should cover whole 128-byte lines: the 2L words of a transform at once where L words are
+    // half a line (32 real q15 points: 0.52 -> see DESIGN 3.3), else the two halves one after the other
+    if constexpr (WHOLE) {
+      rows_out(dst, o, std::integral_constant<int, 2 * L>(), 1, 0);
+    } else {
+      rows_out(dst, o, std::integral_constant<int, L>(), 2, 0);
+      rows_out(dst, o + L, std::integral_constant<int, L>(), 2, 1);
+    }
+  } else {
+    // L + 1 words per transform at a stride of L + 1 words (aligned to the word only): copied linearly, word by word;
+    // a lane's row then starts at an odd word stride
+    word *sw = reinterpret_cast<word *>(stage);
+    const word *__restrict__ src = in + (size_t)t0 * (L + 1);
+    const int nwords = nvalid * (L + 1);
+#pragma unroll
+    for (int k = 0; k <= L; k++) {
+      const int w = lane + 64 * k;
+      sw[w] = w < nwords ? src[w] : word{};
+    }
+    __syncthreads();
+    cpx s[L + 1];
+#pragma unroll
+    for (int i = 0; i <= L; i++) s[i] = Q::unpack(sw[lane * (L + 1) + i]);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < L; i++) x[i] = split_inv(s[i], s[L - i], Q::unpack(coefA[i * mod]), Q::unpack(coefB[i * mod]));
+    transform(x);
+    word o[L];
+#pragma unroll
+    for (int i = 0; i < L; i++) o[i] = Q::pack(sat_shl1(bin(x, i)));
+    rows_out(out + (size_t)t0 * L, o, std::integral_constant<int, L>(), 1, 0);
+  }
+}
+
+template <class Q, int LOGN, bool INV>
+static hipError_t launch_rfft_fixed_lane(const typename Q::word *in, typename Q::word *out, const typename Q::tword *tw,
+                                         const typename Q::tword *A, const typename Q::tword *B, int mod, uint32_t batch, hipStream_t stream)
+{
+  const uint32_t groups = (batch + 63u) / 64u;
+  const uint32_t gx = groups < 65536u ? groups : 65536u, gy = (groups + gx - 1) / gx;
+  note_kernel(ARMFFT_KNAME_Q("rfft_fixed_lane_kernel"), false, LOGN);
+  rfft_fixed_lane_kernel<Q, LOGN, INV><<<dim3(gx, gy, 1), 64, 0, stream>>>(in, out, tw, A, B, mod, batch);
+  return hipGetLastError();
 }
 
 template <class Q, int LOGN, bool INV>
@@ -1401,7 +1616,21 @@ static hipError_t launch_rfft_fixed(int logl, const typename Q::word *in, typena
   case L:    \
     return inverse ? launch_rfft_fixed_direct<Q, L, true>(in, out, tw, A, B, mod, batch, stream) \
                    : launch_rfft_fixed_direct<Q, L, false>(in, out, tw, A, B, mod, batch, stream);
-      D(9) D(10) D(11) D(12)   // (256 complex points: 0.34 against 0.45 of the roofline, stays on the LDS form)
+#ifndef ARMFFT_NO_D9
+      D(9)
+#endif
+      D(10) D(11) D(12)   // (256 complex points: 0.34 against 0.45 of the roofline, stays on the LDS form)
+#undef D
+#define D(L) \
+  case L:    \
+    return inverse ? launch_rfft_fixed_lane<Q, L, true>(in, out, tw, A, B, mod, batch, stream) \
+                   : launch_rfft_fixed_lane<Q, L, false>(in, out, tw, A, B, mod, batch, stream);
+      D(4)
+    case 5:  // 64 real q31 points need 200 registers per lane in this form: 0.51 against 0.63 on the LDS form
+      if (sizeof(typename Q::scalar) == 2)
+        return inverse ? launch_rfft_fixed_lane<Q, 5, true>(in, out, tw, A, B, mod, batch, stream)
+                       : launch_rfft_fixed_lane<Q, 5, false>(in, out, tw, A, B, mod, batch, stream);
+      break;
 #undef D
     }
   }
