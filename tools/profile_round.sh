@@ -17,7 +17,7 @@ run kt_cfft 240 --kernel-trace --stats --output-format csv -d "$OUT/kt_cfft" -- 
 run pmc_fetch 120 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 bench.py --no-cpu-baseline --no-extra --steps 3 --warmup 1 || exit 1
 run pmc_write 120 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 bench.py --no-cpu-baseline --no-extra --steps 3 --warmup 1 || exit 1
 python3 tools/summarize_prof.py "$OUT" "$OUT/cfft_f32_4096x65536.txt" cfft_f32_ > /dev/null || exit 1
-for wl in cfft_q15_4096x65536 cfft_q31_4096x65536 rfft_f32_16384x16384 cfft_f32_4194304x8 cfft_f32_4194304x64 gnss_acq_gps_l1_x256; do
+for wl in cfft_q15_4096x65536 cfft_q31_4096x65536 cfft_q31_16384x16384 rfft_f32_16384x16384 rfft_q15_32x8388608 rfft_q15_1024x262144 rfft_q31_512x524288 cfft_f32_4194304x8 cfft_f32_4194304x64 gnss_acq_gps_l1_x256; do
   run kt_$wl 240 --kernel-trace --stats --output-format csv -d "$OUT/kt_$wl" -- python3 bench.py --no-cpu-baseline --no-extra --workload $wl --steps 20 --warmup 5 || exit 1
   python3 tools/summarize_prof.py "$OUT/kt_$wl" "$OUT/$wl.txt" > /dev/null
 done
