@@ -38,6 +38,31 @@ struct Q31 {
   static __device__ __forceinline__ word pack(cpx c) { return make_int2(c.re, c.im); }
 };
 
+// 16-byte global accesses of streams that are touched once: non-temporal.  Same-box A/B against plain accesses, LDS form:
+// cfft q15 16 / 64 / 256 points 0.71 / 0.725 / 0.72 -> 0.805 / 0.80 / 0.76 of the roofline, q31 16 points 0.71 -> 0.78, real
+// transforms +1 ... +6 %.  The lane form keeps plain accesses (32 real q15 points 0.79 against 0.73 either way).
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+template <bool NT = true>
+__device__ __forceinline__ uint4 ld16_stream(const void *p)
+{
+  if constexpr (NT) {
+    const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(p));
+    return make_uint4(v[0], v[1], v[2], v[3]);
+  } else {
+    return *reinterpret_cast<const uint4 *>(p);
+  }
+}
+template <bool NT = true>
+__device__ __forceinline__ void st16_stream(void *p, uint4 v)
+{
+  if constexpr (NT) {
+    u32x4_t w;
+    w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+    __builtin_nontemporal_store(w, reinterpret_cast<u32x4_t *>(p));
+  } else {
+    *reinterpret_cast<uint4 *>(p) = v;
+  }
+}
 __device__ __forceinline__ int ssat16(int v) { return v > 32767 ? 32767 : (v < -32768 ? -32768 : v); }
 __device__ __forceinline__ int32_t wadd(int32_t a, int32_t b) { return (int32_t)((uint32_t)a + (uint32_t)b); }
 __device__ __forceinline__ int32_t wsub(int32_t a, int32_t b) { return (int32_t)((uint32_t)a - (uint32_t)b); }
@@ -398,7 +423,7 @@ __device__ __forceinline__ void fixed_one_group(typename Q::word *__restrict__ d
   for (int v = tid; v < PL::ELEMS / PER16; v += PL::T) {
     const int e = v * PER16;
     if ((uint32_t)e < nvalid) {
-      const uint4 raw = *reinterpret_cast<const uint4 *>(data + gbase + e);
+      const uint4 raw = ld16_stream(data + gbase + e);
       const word *pw = reinterpret_cast<const word *>(&raw);
 #pragma unroll
       for (int k = 0; k < PER16; k++) lds[fpad(e + k)] = pw[k];
@@ -444,7 +469,7 @@ __device__ __forceinline__ void fixed_one_group(typename Q::word *__restrict__ d
       if (PL::BY2) c = shl1<Q>(c);  // final << 1 of radix4by2 (arm_cfft_q15.c:814-831, arm_cfft_q31.c:807-824)
       pw[k] = Q::pack(c);
     }
-    *reinterpret_cast<uint4 *>(data + gbase + e) = raw;
+    st16_stream(data + gbase + e, raw);
   }
 }
 
@@ -1181,7 +1206,7 @@ __global__ __launch_bounds__(FixedPlan<LOGN>::T, ARMFFT_RFFT_MINW) void rfft_fix
     for (int v = tid; v < PL::ELEMS / PER16; v += PL::T) {
       const int e = v * PER16;
       uint4 raw = make_uint4(0u, 0u, 0u, 0u);
-      if ((uint32_t)(e >> LOGN) < nvt) raw = *reinterpret_cast<const uint4 *>(src + e);
+      if ((uint32_t)(e >> LOGN) < nvt) raw = ld16_stream(src + e);
       const word *pw = reinterpret_cast<const word *>(&raw);
 #pragma unroll
       for (int k = 0; k < PER16; k++) lds[fpad(e + k)] = pw[k];
@@ -1296,11 +1321,11 @@ __global__ __launch_bounds__(FixedPlan<LOGN>::T, ARMFFT_RFFT_MINW) void rfft_fix
 #pragma unroll
         for (int k = 0; k < SPER; k++)
           if (i0 + k != 0) d[2 * L - i0 - k] = Q::pack(mirror(Q::unpack(w[k])));
-        if constexpr (SPER > 1) *reinterpret_cast<uint4 *>(d + i0) = raw;
+        if constexpr (SPER > 1) st16_stream(d + i0, raw);
         else d[i0] = pw[0];
       } else if constexpr (SPER > 1) {
-        *reinterpret_cast<uint4 *>(d + i0) = raw;
-        *reinterpret_cast<uint4 *>(d + 2 * L - i0 - SPER) = rawm;
+        st16_stream(d + i0, raw);
+        st16_stream(d + 2 * L - i0 - SPER, rawm);
       } else {
         d[i0] = pw[0];
         d[2 * L - i0 - 1] = pm[0];
@@ -1447,7 +1472,7 @@ __global__ __launch_bounds__(64) void rfft_fixed_lane_kernel(const typename Q::w
     for (int k = 0; k < CPR; k++) {
       const int v = lane + 64 * k, row = v / CPR, col = v % CPR;
       uint4 raw = make_uint4(0u, 0u, 0u, 0u);
-      if (row < nvalid) raw = reinterpret_cast<const uint4 *>(src)[v];
+      if (row < nvalid) raw = ld16_stream<false>(reinterpret_cast<const uint4 *>(src) + v);
       *reinterpret_cast<uint4 *>(stage + row * ROWB + col * 16) = raw;
     }
     __syncthreads();
@@ -1476,7 +1501,7 @@ __global__ __launch_bounds__(64) void rfft_fixed_lane_kernel(const typename Q::w
     for (int k = 0; k < CP; k++) {
       const int v = lane + 64 * k, row = v / CP, col = v % CP;
       if (row < nvalid)
-        reinterpret_cast<uint4 *>(dst)[(size_t)(row * rows_per_transform + h) * CP + col] = *reinterpret_cast<const uint4 *>(stage + row * RB + col * 16);
+        st16_stream<false>(reinterpret_cast<uint4 *>(dst) + (size_t)(row * rows_per_transform + h) * CP + col, *reinterpret_cast<const uint4 *>(stage + row * RB + col * 16));
     }
     __syncthreads();
   };
