@@ -26,8 +26,8 @@ Extra objects on that line:
                   each the median of 5 repeats.
   extra        -- the other BASELINE.json configs measured the same way in the same run, a few steps each, on
                   EVERY rank (batches / scenes per GPU, barrier + max over ranks like the headline): cfft_q15 /
-                  cfft_q31 4096x65536, rfft_f32 16384x16384, the four-step 2^22 x 8 (config 4) and x 64 (beyond the
-                  Infinity Cache), GNSS acquisition x256 scenes per GPU (config 5) and, with more than one rank, config 5
+                  cfft_q31 4096x65536, cfft_q31 16384x16384 (the fork's goal size), rfft_f32 16384x16384, rfft_q15
+                  1024x262144, the four-step 2^22 x 8 (config 4) and x 64 (beyond the Infinity Cache), GNSS acquisition x256 scenes per GPU (config 5) and, with more than one rank, config 5
                   sharded the other way: Doppler bins per GPU + the all-gather of the winners, checked against the
                   single-rank search (`merged_equals_single_rank_search`).  Each entry carries value, ms_per_step,
                   the slowest and fastest rank's step time and its own roofline object.  The headline `value` /
@@ -572,8 +572,8 @@ def roofline_of(w, launch_s, traffic_table):
             "avg_launch_ms": round(1e3 * launch_s, 4)}
 
 
-EXTRA_WORKLOADS = ["cfft_q15_4096x65536", "cfft_q31_4096x65536", "rfft_f32_16384x16384", "cfft_f32_4194304x8", "cfft_f32_4194304x64",
-                   "gnss_acq_gps_l1_x256"]
+EXTRA_WORKLOADS = ["cfft_q15_4096x65536", "cfft_q31_4096x65536", "cfft_q31_16384x16384", "rfft_f32_16384x16384", "rfft_q15_1024x262144",
+                   "cfft_f32_4194304x8", "cfft_f32_4194304x64", "gnss_acq_gps_l1_x256"]
 
 
 def make_doppler_sharded(w, ctx):

@@ -72,8 +72,9 @@ def test_bench_extras_run_on_the_distributed_path_with_one_rank():
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     names = [e["workload"] for e in line["extra"]]
-    assert names == ["cfft_q15_4096x65536", "cfft_q31_4096x65536", "rfft_f32_16384x16384", "cfft_f32_4194304x8", "cfft_f32_4194304x64",
-                     "gnss_acq_gps_l1_x256", "gnss_acq_gps_l1_x256 (Doppler-sharded)"]
+    assert names == ["cfft_q15_4096x65536", "cfft_q31_4096x65536", "cfft_q31_16384x16384", "rfft_f32_16384x16384", "rfft_q15_1024x262144",
+                     "cfft_f32_4194304x8", "cfft_f32_4194304x64", "gnss_acq_gps_l1_x256", "gnss_acq_gps_l1_x256 (Doppler-sharded)"]
     assert all(e["value"] > 0 and e["n_gpus"] == 1 for e in line["extra"])
     assert line["extra"][-1]["merged_equals_single_rank_search"] is True
-    assert line["extra"][3]["roofline"]["kernel"].count("fourstep_tile_kernel<11") == 2
+    assert line["extra"][5]["roofline"]["kernel"].count("fourstep_tile_kernel<11") == 2
+    assert line["extra"][4]["roofline"]["kernel"] == "rfft_fixed_direct_kernel<armfft::Q15, 9, false>"
