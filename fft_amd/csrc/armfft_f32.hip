@@ -568,10 +568,13 @@ static hipError_t launch_cfft_one(float2 *data, const float2 *tw, uint32_t batch
   return hipGetLastError();
 }
 
+static hipError_t launch_cfft_lane32(float2 *data, uint32_t batch, bool inverse, hipStream_t stream);   // below
+
 hipError_t launch_cfft_f32(int logn, float2 *data, const float2 *tw, uint32_t batch, bool inverse, int order,
                            hipStream_t stream)
 {
   if (batch == 0) return hipSuccess;
+  if (logn == 5 && order == 0) return launch_cfft_lane32(data, batch, inverse, stream);
   switch (logn) {
 #define C(L) \
   case L: return inverse ? launch_cfft_one<L, true>(data, tw, batch, order, stream) : launch_cfft_one<L, false>(data, tw, batch, order, stream);
@@ -579,6 +582,146 @@ hipError_t launch_cfft_f32(int logn, float2 *data, const float2 *tw, uint32_t ba
 #undef C
   }
   return hipErrorInvalidValue;
+}
+
+// 32 complex points, natural order, lane form: one lane per transform.  n = 2a + b: two 16-point butterflies, the odd half times
+// W_32^q (constants in scalar register pairs), one radix-2 layer -- no exchange, no twiddle table; LDS only stages the 256-byte
+// rows of a wave's 64 transforms (see rfft_f32_lane32_kernel below).  The two-pass LDS form ran at 0.72 of the roofline.
+__device__ __forceinline__ float2 cmul_k(float2 a, float cr, float ci)
+{
+  const v2f w = {cr, ci};
+  v2f t, r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(tov(a)), "s"(w));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] neg_lo:[0,0,1]" : "=v"(r) : "v"(tov(a)), "s"(w), "v"(t));
+  return tof(r);
+}
+__device__ constexpr float kCos32[9] = {1.0f, 0.98078528040323043058f, 0.92387953251128673848f, 0.83146961230254523567f, 0.70710678118654757274f,
+                                        0.55557023301960228867f, 0.38268343236508983729f, 0.19509032201612833135f, 0.0f};
+constexpr float cos32(int m) { return m <= 8 ? kCos32[m] : -kCos32[16 - m]; }   // m = 0 .. 16
+constexpr float sin32(int m) { return m <= 8 ? kCos32[8 - m] : kCos32[m - 8]; }
+
+template <bool INV>
+__global__ __launch_bounds__(64) void cfft_f32_lane32_kernel(float2 *data, uint32_t batch)
+{
+  constexpr int N = 32, HALFB = N * 4 + 16, CPH = 8;   // a row is staged in two halves of 128 bytes (8 chunks of 16 bytes): whole lines, half the LDS
+  __shared__ __attribute__((aligned(16))) unsigned char stage[64 * HALFB];
+  const int lane = threadIdx.x;
+  const uint32_t t0 = (blockIdx.x + blockIdx.y * gridDim.x) * 64u;
+  if (t0 >= batch) return;
+  const int nvalid = batch - t0 < 64u ? (int)(batch - t0) : 64;
+  f32x4 *p = reinterpret_cast<f32x4 *>(data + (size_t)t0 * N);
+  float2 e[16], o[16];
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+#pragma unroll
+    for (int k = 0; k < CPH; k++) {
+      const int v = lane + 64 * k, row = v / CPH, col = v % CPH;
+      f32x4 raw = {0.f, 0.f, 0.f, 0.f};
+      if (row < nvalid) raw = __builtin_nontemporal_load(p + row * 2 * CPH + h * CPH + col);
+      *reinterpret_cast<f32x4 *>(stage + row * HALFB + col * 16) = raw;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < CPH; k++) {
+      const f32x4 r = *reinterpret_cast<const f32x4 *>(stage + lane * HALFB + k * 16);
+      e[h * CPH + k] = make_float2(r[0], INV ? -r[1] : r[1]);
+      o[h * CPH + k] = make_float2(r[2], INV ? -r[3] : r[3]);
+    }
+    __syncthreads();
+  }
+  butterfly<16, ArPk>(e);
+  butterfly<16, ArPk>(o);
+  float2 x[N];
+#pragma unroll
+  for (int q = 0; q < 16; q++) {
+    const float2 w = q == 0 ? o[0] : (q == 8 ? ArPk::mul_mi(o[8]) : cmul_k(o[q], cos32(q), -sin32(q)));
+    x[q] = ArPk::cadd(e[q], w);
+    x[q + 16] = ArPk::csub(e[q], w);
+  }
+  constexpr float inv_n = 1.0f / (float)N;
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+#pragma unroll
+    for (int k = 0; k < CPH; k++) {
+      const int i = 2 * (h * CPH + k);
+      f32x4 w;
+      w[0] = x[i].x; w[1] = x[i].y; w[2] = x[i + 1].x; w[3] = x[i + 1].y;
+      if (INV) { w[0] *= inv_n; w[1] *= -inv_n; w[2] *= inv_n; w[3] *= -inv_n; }
+      *reinterpret_cast<f32x4 *>(stage + lane * HALFB + k * 16) = w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < CPH; k++) {
+      const int v = lane + 64 * k, row = v / CPH, col = v % CPH;
+      if (row < nvalid) __builtin_nontemporal_store(*reinterpret_cast<const f32x4 *>(stage + row * HALFB + col * 16), p + row * 2 * CPH + h * CPH + col);
+    }
+    __syncthreads();
+  }
+}
+
+static hipError_t launch_cfft_lane32(float2 *data, uint32_t batch, bool inverse, hipStream_t stream)
+{
+  const dim3 grid = grid_for((batch + 63u) / 64u);
+  note_kernel(inverse ? "cfft_f32_lane32_kernel<true>" : "cfft_f32_lane32_kernel<false>", false);
+  if (inverse) cfft_f32_lane32_kernel<true><<<grid, 64, 0, stream>>>(data, batch);
+  else cfft_f32_lane32_kernel<false><<<grid, 64, 0, stream>>>(data, batch);
+  return hipGetLastError();
+}
+
+// 32 real points, forward, lane form: ONE LANE PER TRANSFORM (the fixed-point real FFT's lane kernel, armfft_fixed.hip).  The 16
+// complex points are one radix-16 butterfly on the lane's registers, both operands of every split bin are already there, the split
+// factors have the same index in every lane (scalar loads), and LDS only turns the 128-byte rows of a wave's 64 transforms into
+// lane-contiguous 16-byte accesses (rows padded by 16 bytes: conflict-free 16-byte row accesses).
+__global__ __launch_bounds__(64) void rfft_f32_lane32_kernel(const float2 *__restrict__ in, float2 *__restrict__ out, const float2 *__restrict__ twr,
+                                                             uint32_t batch)
+{
+  constexpr int M = 16, ROWB = M * 8 + 16, CPR = 8;   // 16-byte chunks per row
+  __shared__ __attribute__((aligned(16))) unsigned char stage[64 * ROWB];
+  const int lane = threadIdx.x;
+  const uint32_t t0 = (blockIdx.x + blockIdx.y * gridDim.x) * 64u;
+  if (t0 >= batch) return;
+  const int nvalid = batch - t0 < 64u ? (int)(batch - t0) : 64;
+  const f32x4 *__restrict__ pi = reinterpret_cast<const f32x4 *>(in + (size_t)t0 * M);
+  f32x4 *__restrict__ po = reinterpret_cast<f32x4 *>(out + (size_t)t0 * M);
+#pragma unroll
+  for (int k = 0; k < CPR; k++) {
+    const int v = lane + 64 * k, row = v / CPR, col = v % CPR;
+    f32x4 raw = {0.f, 0.f, 0.f, 0.f};
+    if (row < nvalid) raw = __builtin_nontemporal_load(pi + v);
+    *reinterpret_cast<f32x4 *>(stage + row * ROWB + col * 16) = raw;
+  }
+  __syncthreads();
+  float2 z[M];
+#pragma unroll
+  for (int k = 0; k < CPR; k++) {
+    const f32x4 r = *reinterpret_cast<const f32x4 *>(stage + lane * ROWB + k * 16);
+    z[2 * k] = make_float2(r[0], r[1]);
+    z[2 * k + 1] = make_float2(r[2], r[3]);
+  }
+  __syncthreads();
+  butterfly<16, ArPk>(z);
+  // split of stage_rfft_f32 (arm_rfft_fast_f32.c:316-402), as in rfft_f32_kernel
+  float2 o[M];
+  o[0] = make_float2(z[0].x + z[0].y, z[0].x - z[0].y);
+#pragma unroll
+  for (int k = 1; k < M; k++) {
+    const float2 A = z[k], B = z[M - k], c = twr[k];   // (sin, cos)
+    const float a = B.x - A.x, b = B.y + A.y;
+    o[k].x = 0.5f * (A.x + B.x + c.x * a + c.y * b);
+    o[k].y = 0.5f * (A.y - B.y + c.y * a - c.x * b);
+  }
+#pragma unroll
+  for (int k = 0; k < CPR; k++) {
+    f32x4 w;
+    w[0] = o[2 * k].x; w[1] = o[2 * k].y; w[2] = o[2 * k + 1].x; w[3] = o[2 * k + 1].y;
+    *reinterpret_cast<f32x4 *>(stage + lane * ROWB + k * 16) = w;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < CPR; k++) {
+    const int v = lane + 64 * k, row = v / CPR, col = v % CPR;
+    if (row < nvalid) __builtin_nontemporal_store(*reinterpret_cast<const f32x4 *>(stage + row * ROWB + col * 16), po + v);
+  }
 }
 
 template <int LOGM, bool INV>
@@ -608,6 +751,12 @@ hipError_t launch_rfft_f32(int logn_real, const float *in, float *out, const flo
   if (batch == 0) return hipSuccess;
   const float2 *i2 = reinterpret_cast<const float2 *>(in);
   float2 *o2 = reinterpret_cast<float2 *>(out);
+  if (logn_real == 5 && !inverse) {
+    const uint32_t groups = (batch + 63u) / 64u;
+    note_kernel("rfft_f32_lane32_kernel", false);
+    rfft_f32_lane32_kernel<<<grid_for(groups), 64, 0, stream>>>(i2, o2, tw_r, batch);
+    return hipGetLastError();
+  }
   switch (logn_real - 1) {
 #define C(L) \
   case L: return inverse ? launch_rfft_one<L, true>(i2, o2, tw_c, tw_r, batch, stream) : launch_rfft_one<L, false>(i2, o2, tw_c, tw_r, batch, stream);
