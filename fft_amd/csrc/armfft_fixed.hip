@@ -523,7 +523,18 @@ __global__ __launch_bounds__(FixedPlan<LOGN>::T, 4) void cfft_fixed_kernel(typen
 // last step's stores.  An odd number of stages between the first step and the last pair (8192) runs one single-stage
 // step first.
 // ------------------------------------------------------------------------------------------
-template <int LOGN>
+namespace dtw {   // twiddle tables of the direct form's middle stages, see DirectPlan
+constexpr int nbf(int logl, int s) { return 1 << (logl - 2 * s - 2); }
+constexpr bool compact(int logl, int m, int s1, int s) { return s >= s1 && s <= m - 3 && nbf(logl, s) <= 64; }
+constexpr bool any_quarter(int logl, int m, int s1, int s) { return s > m - 3 ? false : (!compact(logl, m, s1, s) || any_quarter(logl, m, s1, s + 1)); }
+constexpr int coff(int logl, int m, int s1, int tl4, int s)
+{
+  return s <= s1 ? tl4 : coff(logl, m, s1, tl4, s - 1) + (compact(logl, m, s1, s - 1) ? 3 * nbf(logl, s - 1) : 0);
+}
+}  // namespace dtw
+
+// CT: the late middle stages read compact twiddle tables (see below); chosen per element type and size (DirectTune)
+template <int LOGN, bool CT = false>
 struct DirectPlan {
   static_assert(LOGN >= 8 && LOGN <= 14, "direct form: 256 ... 16384 points");
   static constexpr bool BY2 = (LOGN & 1) != 0;
@@ -540,7 +551,30 @@ struct DirectPlan {
   // offset of point e0 + (c << LOGQ) from pad(e0): exact whenever those points stay inside one aligned block of
   // 2^(LOGQ+4) points that e0 starts with a remainder below 2^LOGQ (see the steps)
   static constexpr int doff(int c, int logq) { return (c << logq) + ((c << logq) >> SH); }
+  // ---- twiddles of the middle steps (stages S1 .. M-3) in LDS ----
+  // A stage with few distinct butterflies (nbf <= 64: the last two middle stages) reads a COMPACT table of its own,
+  // T[3 a + r - 1] = tw[r a MOD_S] for butterfly a: the three twiddles of a butterfly are adjacent, consecutive butterflies
+  // three words apart -- conflict-free for any set of lanes.  Read from the every-fourth copy instead (index a MOD_S r / 4),
+  // their few distinct addresses fall into one or two banks: 8- and 16-way conflicts, 58 % of all LDS cycles of the
+  // 16384-point q15 kernel (profiles/r03_pmc_sq_cfft_q15_16384.txt).  The earlier middle stages (8192 and 16384 points only)
+  // keep the every-fourth copy (strides 1 ... 12 words across the lanes).
+  static constexpr int S1 = (BY2 || (M & 1)) ? 1 : 2;                                   // first middle stage
+  static constexpr int nbf(int s) { return dtw::nbf(LOGL, s); }                         // distinct butterflies of stage s
+  static constexpr bool compact(int s) { return CT && dtw::compact(LOGL, M, S1, s); }
+  static constexpr int TL4 = (!CT || dtw::any_quarter(LOGL, M, S1, S1)) ? 3 * N / 16 : 0;   // entries of the every-fourth copy
+  static constexpr int coff(int s) { return CT ? dtw::coff(LOGL, M, S1, TL4, s) : TL4; }      // first entry of stage s's compact table
+  static constexpr int TL_ENTRIES = CT ? dtw::coff(LOGL, M, S1, TL4, M - 2 > S1 ? M - 2 : S1) : TL4;
 };
+// Same-box A/B of the compact tables, bit-exact either way: q15 4096 points 0.667 -> 0.694 of the roofline, 16384 0.515 -> 0.554;
+// 1024 / 8192 points and every q31 size lose 2-5 % (the tables' gathered fill costs more than their reads save) and keep the
+// every-fourth copy alone.
+template <class Q, int LOGN> struct DirectTune { static constexpr bool COMPACT = false; };
+template <> struct DirectTune<Q15, 12> { static constexpr bool COMPACT = true; };
+template <> struct DirectTune<Q15, 14> { static constexpr bool COMPACT = true; };
+template <class Q, int LOGN> using DPlan = DirectPlan<LOGN, DirectTune<Q, LOGN>::COMPACT>;
+template <class TW> struct TlCompact { const TW *t; };
+template <class T> struct is_compact : std::false_type {};
+template <class TW> struct is_compact<TlCompact<TW>> : std::true_type {};
 
 // (blk, j) of thread tid in a middle step over blocks of 2^LOGN1 points (j < 2^(LOGN1-4)): any bijection is allowed, the
 // step is in place per thread.  The word address is (blk << LOGN1) + j + const + its own >> SH, so lane bit k (k < 5) is
@@ -577,12 +611,19 @@ __device__ __forceinline__ void stage_butterflies(typename Q::cpx *x, int j, TWS
 #pragma unroll
   for (int b = 0; b < 4; b++) {
     cpx y[4] = {x[b], x[4 + b], x[8 + b], x[12 + b]};
-    const int ic = (j + (b << LOGQ)) * MOD_S;
     cpx w1{}, w2{}, w3{};
-    if (StageKind<S, M>::value != 2) {
-      w1 = Q::unpack(tws(ic));
-      w2 = Q::unpack(tws(2 * ic));
-      w3 = Q::unpack(tws(3 * ic));
+    if constexpr (StageKind<S, M>::value != 2) {
+      if constexpr (is_compact<TWS>::value) {
+        const int a3 = 3 * (j + (b << LOGQ));
+        w1 = Q::unpack(tws.t[a3]);
+        w2 = Q::unpack(tws.t[a3 + 1]);
+        w3 = Q::unpack(tws.t[a3 + 2]);
+      } else {
+        const int ic = (j + (b << LOGQ)) * MOD_S;
+        w1 = Q::unpack(tws(ic));
+        w2 = Q::unpack(tws(2 * ic));
+        w3 = Q::unpack(tws(3 * ic));
+      }
     }
     bfly<Q, StageKind<S, M>::value, INV>(y, w1, w2, w3);
     x[b] = y[0]; x[4 + b] = y[1]; x[8 + b] = y[2]; x[12 + b] = y[3];
@@ -598,11 +639,17 @@ __device__ __forceinline__ void pair_butterflies(typename Q::cpx *x, int j, TWS 
   constexpr int MOD_S1 = TWMOD0 << (2 * (S + 1));
   stage_butterflies<Q, LOGL, S, INV, TWMOD0>(x, j, tws);
   cpx w1{}, w2{}, w3{};
-  if (StageKind<S + 1, M>::value != 2) {
-    const int ic = j * MOD_S1;
-    w1 = Q::unpack(tws1(ic));
-    w2 = Q::unpack(tws1(2 * ic));
-    w3 = Q::unpack(tws1(3 * ic));
+  if constexpr (StageKind<S + 1, M>::value != 2) {
+    if constexpr (is_compact<TWS1>::value) {
+      w1 = Q::unpack(tws1.t[3 * j]);
+      w2 = Q::unpack(tws1.t[3 * j + 1]);
+      w3 = Q::unpack(tws1.t[3 * j + 2]);
+    } else {
+      const int ic = j * MOD_S1;
+      w1 = Q::unpack(tws1(ic));
+      w2 = Q::unpack(tws1(2 * ic));
+      w3 = Q::unpack(tws1(3 * ic));
+    }
   }
 #pragma unroll
   for (int a = 0; a < 4; a++) bfly<Q, StageKind<S + 1, M>::value, INV>(&x[4 * a], w1, w2, w3);
@@ -613,7 +660,7 @@ __device__ __forceinline__ void pair_butterflies(typename Q::cpx *x, int j, TWS 
 template <class Q, int LOGN, int S, bool INV>
 __device__ __forceinline__ void direct_middle(typename Q::word *lds, const typename Q::tword *tl, int tid)
 {
-  using PL = DirectPlan<LOGN>;
+  using PL = DPlan<Q, LOGN>;
   using cpx = typename Q::cpx;
   if constexpr (S < PL::M - 2) {
     constexpr bool PAIR = ((PL::M - 2 - S) % 2) == 0;
@@ -626,8 +673,14 @@ __device__ __forceinline__ void direct_middle(typename Q::word *lds, const typen
 #pragma unroll
     for (int c = 0; c < 16; c++) x[c] = Q::unpack(base[PL::doff(c, LOGQ)]);
     auto t4 = [&](int ic) { return tl[ic >> 2]; };
-    if constexpr (PAIR) pair_butterflies<Q, PL::LOGL, S, INV, PL::TWMOD0>(x, j, t4, t4);
-    else stage_butterflies<Q, PL::LOGL, S, INV, PL::TWMOD0>(x, j, t4);
+    const TlCompact<typename Q::tword> c0{tl + PL::coff(S)}, c1{tl + PL::coff(S + 1)};
+    auto run = [&](auto twa, auto twb) {
+      if constexpr (PAIR) pair_butterflies<Q, PL::LOGL, S, INV, PL::TWMOD0>(x, j, twa, twb);
+      else stage_butterflies<Q, PL::LOGL, S, INV, PL::TWMOD0>(x, j, twa);
+    };
+    if constexpr (PL::compact(S)) run(c0, c1);                      // (a compact stage is followed by compact stages)
+    else if constexpr (PAIR && PL::compact(S + 1)) run(t4, c1);
+    else run(t4, t4);
 #pragma unroll
     for (int c = 0; c < 16; c++) base[PL::doff(c, LOGQ)] = Q::pack(x[c]);
     __syncthreads();
@@ -656,6 +709,21 @@ template <> struct DirectIo<Q31> {
   }
 };
 
+template <class Q, int LOGN, int S, class PL = DPlan<Q, LOGN>>
+__device__ __forceinline__ void fill_compact(typename Q::tword *tl, const typename Q::tword *__restrict__ tw, int wtid)
+{
+  if constexpr (S <= PL::M - 3) {
+    if constexpr (PL::compact(S)) {
+      constexpr int MOD_S = PL::TWMOD0 << (2 * S);
+      for (int i = wtid; i < 3 * PL::nbf(S); i += PL::WG) {
+        const int a = i / 3, r = i - 3 * a + 1;
+        tl[PL::coff(S) + i] = tw[r * a * MOD_S];
+      }
+    }
+    fill_compact<Q, LOGN, S + 1, PL>(tl, tw, wtid);
+  }
+}
+
 // The transform itself.  On entry x[c] = point tid + c*T; on return x[c] = the result whose index in bit-reversed
 // (= natural) output order is brev4(c)*T + tid, before the final << 1 of the 2 * 4^k sizes (direct_out).  `lds` = this
 // transform's image (PL::LDS_WORDS words), `tl` = the workgroup's room for 3N/16 table words, tid = thread inside the
@@ -664,14 +732,17 @@ template <class Q, int LOGN, bool INV>
 __device__ __forceinline__ void direct_transform(typename Q::cpx *x, typename Q::word *lds, typename Q::tword *tl,
                                                  const typename Q::tword *__restrict__ tw, int tid, int wtid)
 {
-  using PL = DirectPlan<LOGN>;
+  using PL = DPlan<Q, LOGN>;
   using word = typename Q::word;
   using cpx = typename Q::cpx;
   constexpr int T = PL::T, M = PL::M;
-  // every fourth table entry to LDS for the later stages (twidCoefModifier 4^S, S >= 1)
-  for (int i = wtid; i < 3 * PL::N / 16; i += PL::WG) tl[i] = tw[4 * i];
+  // every fourth table entry to LDS for the middle stages that read it (twidCoefModifier 4^S, S >= 1), compact tables for the others
+  if constexpr (PL::TL4 > 0) {
+    for (int i = wtid; i < PL::TL4; i += PL::WG) tl[i] = tw[4 * i];
+  }
+  fill_compact<Q, LOGN, PL::S1>(tl, tw, wtid);
   auto tg = [&](int ic) { return tw[ic]; };
-  constexpr int S1 = (PL::BY2 || (M & 1)) ? 1 : 2;  // first stage of the middle steps
+  constexpr int S1 = PL::S1;  // first stage of the middle steps
   if constexpr (PL::BY2) {
     // radix-2 pre-stage on (point i, point i + N/2), i = tid + c*T, then stage 0 of both halves: butterfly k of half h
     // over x[8h + k], x[8h + k + 2], x[8h + k + 4], x[8h + k + 6] (points N/8 apart), twiddle index 2 (tid + k*T)
@@ -730,7 +801,7 @@ template <class Q, int LOGN, bool INV>
 __global__ __launch_bounds__(DirectPlan<LOGN>::WG) void cfft_fixed_direct_kernel(typename Q::word *__restrict__ data,
                                                                                 const typename Q::tword *__restrict__ tw, uint32_t batch)
 {
-  using PL = DirectPlan<LOGN>;
+  using PL = DPlan<Q, LOGN>;
   using word = typename Q::word;
   using tword = typename Q::tword;
   using cpx = typename Q::cpx;
@@ -813,6 +884,8 @@ __device__ __forceinline__ void q31_split_steps(Q31::cpx *x, int32_t *lds, const
     dlane_map<LOGN, LOGN1>(tid, blk, j);
     const int base = PL::pad((blk << LOGN1) + j);
     q31_exchange<LOGN, LOGQP, LOGQ>(lds, baseP, base, x);
+    // (compact tables for the last two middle stages, as in the q15 direct form, were measured here too: 4096 / 8192 points -2 %,
+    // 16384 +-0 -- this kernel waits on its exchange barriers, not on the table reads)
     if constexpr (PAIR) {
       if constexpr (LDS_S) pair_butterflies<Q31, PL::LOGL, S, INV, PL::TWMOD0>(x, j, tld, tld);
       else pair_butterflies<Q31, PL::LOGL, S, INV, PL::TWMOD0>(x, j, tg, tld);       // stage S + 1: multiples of 4 * 2^TLS at least
@@ -912,8 +985,8 @@ static hipError_t launch_q31_split(int2 *data, const int2 *tw, uint32_t batch, h
 template <class Q, int LOGN, bool INV>
 static hipError_t launch_fixed_direct(typename Q::word *data, const typename Q::tword *tw, uint32_t batch, hipStream_t stream)
 {
-  using PL = DirectPlan<LOGN>;
-  constexpr size_t lds_bytes = (size_t)PL::TPB * PL::IMG * sizeof(typename Q::word) + (size_t)(3 * PL::N / 16) * sizeof(typename Q::tword);
+  using PL = DPlan<Q, LOGN>;
+  constexpr size_t lds_bytes = (size_t)PL::TPB * PL::IMG * sizeof(typename Q::word) + (size_t)PL::TL_ENTRIES * sizeof(typename Q::tword);
   static_assert(lds_bytes <= 160 * 1024, "direct form: the transforms of a workgroup and the quarter table in LDS");
   static std::atomic<bool> attr_done[16];
   int dev = 0;
@@ -1374,7 +1447,7 @@ __global__ __launch_bounds__(DirectPlan<LOGN>::WG) void rfft_fixed_direct_kernel
                                                                                 const typename Q::tword *__restrict__ coefB, int mod,
                                                                                 uint32_t batch)
 {
-  using PL = DirectPlan<LOGN>;
+  using PL = DPlan<Q, LOGN>;
   using word = typename Q::word;
   using tword = typename Q::tword;
   using cpx = typename Q::cpx;
@@ -1587,8 +1660,8 @@ template <class Q, int LOGN, bool INV>
 static hipError_t launch_rfft_fixed_direct(const typename Q::word *in, typename Q::word *out, const typename Q::tword *tw,
                                            const typename Q::tword *A, const typename Q::tword *B, int mod, uint32_t batch, hipStream_t stream)
 {
-  using PL = DirectPlan<LOGN>;
-  constexpr size_t lds_bytes = (size_t)PL::TPB * PL::IMG * sizeof(typename Q::word) + (size_t)(3 * PL::N / 16) * sizeof(typename Q::tword);
+  using PL = DPlan<Q, LOGN>;
+  constexpr size_t lds_bytes = (size_t)PL::TPB * PL::IMG * sizeof(typename Q::word) + (size_t)PL::TL_ENTRIES * sizeof(typename Q::tword);
   static std::atomic<bool> attr_done[16];
   int dev = 0;
   (void)hipGetDevice(&dev);
