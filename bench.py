@@ -484,7 +484,7 @@ class Ctx:
             return list(vals), list(vals)
         import torch
         import torch.distributed as dist
-        t = torch.tensor(list(vals) + [-v for v in vals], device=self.device, dtype=torch.float64)
+        t = torch.tensor(list(vals) + [-v for v in vals], device="cpu" if REHEARSAL else self.device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         t = t.tolist()
         k = len(vals)
@@ -571,6 +571,11 @@ def roofline_of(w, launch_s, traffic_table):
             "traffic": traffic, "traffic_source": src, "kernel": w.kernel_name, "algorithmic_bytes_per_launch": w.batch * w.bytes_per_xform,
             "avg_launch_ms": round(1e3 * launch_s, 4)}
 
+
+# ARMFFT_BENCH_REHEARSAL=1: the N-rank path on a box with fewer GPUs than ranks -- the ranks share the GPUs (rank r on GPU r mod count)
+# and the collectives run over gloo (RCCL refuses two ranks on one device).  For tests of the launcher, the per-rank extras and the
+# Doppler-sharded merge (tests/test_gpu_rccl_one_rank.py); the line says so in "rehearsal" and its numbers mean nothing.
+REHEARSAL = os.environ.get("ARMFFT_BENCH_REHEARSAL") == "1"
 
 EXTRA_WORKLOADS = ["cfft_q15_4096x65536", "cfft_q31_4096x65536", "cfft_q31_16384x16384", "rfft_f32_16384x16384", "rfft_q15_1024x262144",
                    "cfft_f32_4194304x8", "cfft_f32_4194304x64", "gnss_acq_gps_l1_x256"]
@@ -692,7 +697,7 @@ def launch_ranks(args):
     import socket
     import subprocess
     have = visible_gpus()
-    if have < args.gpus:
+    if have < args.gpus and not (REHEARSAL and have >= 1):
         sys.stderr.write("bench.py: --gpus %d asked for, %d GPU(s) visible on this node: refusing to run (a smaller run would "
                          "print a line that claims n_gpus=%d)\n" % (args.gpus, have, args.gpus))
         return 2
@@ -738,13 +743,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: fft_amd has no CPU path")
-    if local_rank >= torch.cuda.device_count():
+    dev_index = local_rank % max(1, torch.cuda.device_count()) if REHEARSAL else local_rank
+    if dev_index >= torch.cuda.device_count():
         raise SystemExit("bench.py: rank %d has no GPU (LOCAL_RANK %d, %d visible)" % (rank, local_rank, torch.cuda.device_count()))
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(dev_index)
     use_dist = world > 1 or args.force_dist   # --force-dist: the RCCL group, barrier, reductions and all-gather with ONE rank too
     if use_dist:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    assert lib.arm_fft_mi355_set_device(local_rank) == 0, fft_amd.last_error()
+        if REHEARSAL:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+    assert lib.arm_fft_mi355_set_device(dev_index) == 0, fft_amd.last_error()
 
     wl = resolve_workload(args.workload, args.batch)
     K, W = args.steps, args.warmup
@@ -790,6 +799,9 @@ def main():
                               "settled clocks of a sustained run (--preheat-ms 0 disables)" % (head["preheat_launches"], args.preheat_ms, W)},
         "roofline": head["roofline"],
     }
+    if REHEARSAL:
+        line["rehearsal"] = ("%d ranks on %d GPU(s) with gloo collectives (ARMFFT_BENCH_REHEARSAL=1): a check of the N-rank code path, "
+                             "not a measurement" % (world, torch.cuda.device_count()))
     if kind == "gnss":
         line["config"].update(extra_config)
     if shard_doppler:

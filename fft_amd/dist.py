@@ -55,9 +55,12 @@ def merge_best(best, group=None):
     if not (dist.is_available() and dist.is_initialized()):
         return best
     world = dist.get_world_size(group)
-    gathered = [torch.empty_like(best) for _ in range(world)]
-    dist.all_gather(gathered, best.contiguous(), group=group)
-    rows = torch.stack(gathered)                       # [world, n_prn, 8]
+    src = best.contiguous()
+    if src.is_cuda and dist.get_backend(group) == "gloo":
+        src = src.cpu()                                # gloo gathers host tensors (rehearsals of the multi-GPU path without RCCL)
+    gathered = [torch.empty_like(src) for _ in range(world)]
+    dist.all_gather(gathered, src, group=group)
+    rows = torch.stack(gathered).to(best.device)       # [world, n_prn, 8]
     peak = rows[..., 0].view(torch.float32)
     key = torch.where(peak >= 0, rows[..., 0].to(torch.int64) + 1, torch.zeros_like(rows[..., 0], dtype=torch.int64)) << 32
     key = key | (0x7FFFFFFF - rows[..., 4].to(torch.int64))

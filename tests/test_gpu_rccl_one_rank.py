@@ -78,3 +78,26 @@ def test_bench_extras_run_on_the_distributed_path_with_one_rank():
     assert line["extra"][-1]["merged_equals_single_rank_search"] is True
     assert line["extra"][5]["roofline"]["kernel"].count("fourstep_tile_kernel<11") == 2
     assert line["extra"][4]["roofline"]["kernel"] == "rfft_fixed_direct_kernel<armfft::Q15, 9, false>"
+
+
+def test_bench_two_ranks_rehearsal_on_one_gpu():
+    """`python bench.py --gpus 2` end to end with ARMFFT_BENCH_REHEARSAL=1: the launcher starts two ranks, both use this box's GPU,
+    gloo carries the collectives (RCCL refuses two ranks on one device).  Everything else is the N-rank path the driver's
+    2 / 4 / 8-GPU runs take: per-rank workloads, barrier / min / max per measurement, the extras on every rank, config 5 sharded
+    both ways with the merged winners checked against the single-rank search.  The numbers mean nothing (two ranks share a GPU)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", ARMFFT_BENCH_REHEARSAL="1")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--preheat-ms", "10",
+           "--extra-steps", "1"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=170)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and "rehearsal" in line and "cpu_baseline" not in line
+    assert line["ms_per_step_ranks"]["min"] <= line["ms_per_step_ranks"]["max"] == line["ms_per_step"]
+    names = [e["workload"] for e in line["extra"]]
+    assert names[-2:] == ["gnss_acq_gps_l1_x256", "gnss_acq_gps_l1_x256 (Doppler-sharded)"] and len(names) == 9
+    assert all(e["n_gpus"] == 2 and e["value"] > 0 for e in line["extra"])
+    assert line["extra"][-1]["merged_equals_single_rank_search"] is True
+    # whole-job value = two ranks' units over the slower rank's time
+    per_rank = 5.0 * 4096 * 12 * 65536 / (line["ms_per_step"] * 1e-3) / 1e9
+    assert abs(line["value"] - 2 * per_rank) <= 1e-3 * line["value"]
