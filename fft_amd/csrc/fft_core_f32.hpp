@@ -603,13 +603,23 @@ __device__ __forceinline__ void fft_block_preloaded(float2 *v, float2 *lds, cons
 template <class PL>
 struct SplitImage {
   static_assert(PL::TPB == 1, "split exchange: one transform per workgroup");
-  static constexpr int ELEMS = PL::N + (PL::N >> 4);
+#ifndef ARMFFT_SPLIT_PAD
+#define ARMFFT_SPLIT_PAD 5
+#endif
+  // One float of padding per 2^PAD.  The exchange moves 4-byte words: ds_read_b32 / ds_write_b32 are served in two groups of 32
+  // lanes over 32 banks (MI355X_MICROARCH.md, LDS), so the 32 consecutive points a group reads must be 32 consecutive words --
+  // with a pad every 16 (rounds 1-2) every such access had one 2-way conflict per group: 40 % of all LDS cycles of the
+  // 16384-point kernel were conflicts (profiles/r03_pmc_sq_cfft_f32_16384_before.txt), exactly what the bank model gives
+  // (1.67 x the conflict-free cycles; a pad every 32: 1.17 x, and the first pass's stride-16 stores still spread over all banks).
+  // Same-box A/B: 16384 points 0.675 -> 0.69 of the roofline, 4096 and 8192 unchanged (0.748, 0.70): these kernels wait for HBM.
+  static constexpr int PAD = ARMFFT_SPLIT_PAD;
+  static constexpr int ELEMS = PL::N + (PL::N >> PAD);
   static constexpr size_t LDS_BYTES = (size_t)ELEMS * sizeof(float);
   // butterfly w = tid + q*T of a pass with 2^LNR butterflies per transform: its sequence and its index in the sequence
   static __device__ __forceinline__ int seq(int, int) { return 0; }
   static __device__ __forceinline__ int bfly(int w, int lnr) { return w & ((1 << lnr) - 1); }
-  static __device__ __forceinline__ int idx(int, int e) { return e + (e >> 4); }
-  static constexpr int delta(int c) { return c + (c >> 4); }  // c's set bits disjoint from e's (leg strides)
+  static __device__ __forceinline__ int idx(int, int e) { return e + (e >> PAD); }
+  static constexpr int delta(int c) { return c + (c >> PAD); }  // c's set bits disjoint from e's (leg strides)
 };
 
 // The same exchange for TPB sequences per workgroup held INTERLEAVED: butterfly w works on sequence w % TPB, so the lanes
