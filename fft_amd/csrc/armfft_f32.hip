@@ -68,9 +68,22 @@ template <> struct Tune<8> : TuneBase { static constexpr unsigned LAZYMASK = ~0u
 template <> struct Tune<9> : TuneBase { static constexpr unsigned LAZYMASK = ~0u; static constexpr int AUX = 2; static constexpr bool ONESHOT = true; };
 template <> struct Tune<10> : TuneBase { static constexpr unsigned LAZYMASK = ~0u; static constexpr int AUX = 2; static constexpr bool ONESHOT = true; };
 template <> struct Tune<11> : TuneBase { static constexpr unsigned LAZYMASK = ~0u; static constexpr int MINW = 3, AUX = 2; static constexpr bool ONESHOT = true; };
+// Points per thread of the SPLIT sizes (Plan::E): 32 at 16384 points -- two 512-thread workgroups per CU at 124 VGPRs instead of two
+// 1024-thread ones at 64: half the waves at every exchange barrier, twice the independent work between two barriers.  Same-box
+// A/B: 16384 points 0.690 -> 0.705 of the roofline; 8192 points +-0 (0.72), 4096 points 0.745 -> 0.62 (20 bytes of spills at 128
+// VGPRs, and seven two-wave workgroups per CU cover less than seven four-wave ones): those stay at 16.
+#ifndef ARMFFT_F32_E12
+#define ARMFFT_F32_E12 16
+#endif
+#ifndef ARMFFT_F32_E13
+#define ARMFFT_F32_E13 16
+#endif
 template <> struct Tune<12> : TuneBase { static constexpr unsigned LAZYMASK = ~0u; static constexpr int AUX = 2; static constexpr bool ONESHOT = true, SPLIT = true, NESTED16 = true; };
 template <> struct Tune<13> : TuneBase { static constexpr unsigned LAZYMASK = ~0u; static constexpr int AUX = 2; static constexpr bool ONESHOT = true, SPLIT = true; };
-template <> struct Tune<14> : TuneBase { static constexpr unsigned LAZYMASK = ~0u; static constexpr int MINW = 8, AUX = 2; static constexpr bool ONESHOT = true, SPLIT = true, NESTED16 = true; };
+#ifndef ARMFFT_F32_E14
+#define ARMFFT_F32_E14 32
+#endif
+template <> struct Tune<14> : TuneBase { static constexpr unsigned LAZYMASK = ~0u; static constexpr int MINW = 8 * 16 / ARMFFT_F32_E14, AUX = 2; static constexpr bool ONESHOT = true, SPLIT = true, NESTED16 = true; };
 
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
@@ -80,7 +93,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // wave: 256 and 512 points put 4 / 2 transforms in it); the staged and plain kernels below 256
 // points use single-wave workgroups too.
 // (packed arithmetic everywhere but at 128, 512, 2048, 4096 and 8192 points (same-box A/B per size): see ArPk / ArSc)
-template <int LOGN> using CPlan = Plan<LOGN, LOGN <= 7 ? 64 : (Tune<LOGN>::ONESHOT && LOGN < 12) ? ((1 << LOGN) / 16 < 64 ? 64 : (1 << LOGN) / 16) : 0, false, !(LOGN == 7 || LOGN == 9 || (LOGN >= 11 && LOGN <= 13))>;
+template <int LOGN> constexpr int kSplitE = LOGN == 14 ? ARMFFT_F32_E14 : LOGN == 13 ? ARMFFT_F32_E13 : LOGN == 12 ? ARMFFT_F32_E12 : 16;   // points per thread
+template <int LOGN> using CPlan = Plan<LOGN, LOGN >= 12 ? (1 << LOGN) / kSplitE<LOGN> : LOGN <= 7 ? 64 : (Tune<LOGN>::ONESHOT && LOGN < 12) ? ((1 << LOGN) / 16 < 64 ? 64 : (1 << LOGN) / 16) : 0, false, !(LOGN == 7 || LOGN == 9 || (LOGN >= 11 && LOGN <= 13)), kSplitE<LOGN>>;
 
 // Buffer descriptor over one transform (gfx9 raw buffer: stride 0, range in bytes, 32-bit data
 // format): address = base + scalar offset + per-lane offset, so the 16 legs of a thread share ONE
@@ -224,7 +238,7 @@ __global__ __launch_bounds__(CPlan<LOGN>::T, Tune<LOGN>::MINW) void cfft_f32_spl
   if (g0 >= batch) return;
   const int tid = threadIdx.x;
   const __amdgpu_buffer_rsrc_t rs = transform_rsrc(data + (size_t)g0 * PL::N, PL::N * (uint32_t)sizeof(float2));
-  float2 v[16];
+  float2 v[PL::E];
   for_each_first_pass_input_split<PL>(tid, [&](int slot, int, int j, int roff) {
     const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(rs, j * 8, roff * 8, Tune<LOGN>::AUX);
     float2 x = make_float2(__uint_as_float(w[0]), __uint_as_float(w[1]));

@@ -849,36 +849,61 @@ __global__ __launch_bounds__(DirectPlan<LOGN>::WG) void cfft_fixed_direct_kernel
 // the quarter table, 12 KiB at 8192; TLS = 4 at 16384, 6 KiB -- the quarter table would push the workgroup past 80 KiB), the
 // others from the global table (L2).
 // ------------------------------------------------------------------------------------------
+#ifndef ARMFFT_Q31_V14
+#define ARMFFT_Q31_V14 2
+#endif
+#ifndef ARMFFT_Q31_V13
+#define ARMFFT_Q31_V13 1
+#endif
+#ifndef ARMFFT_Q31_V12
+#define ARMFFT_Q31_V12 1
+#endif
 template <int LOGN>
 struct SplitQ31 {
   using PL = DirectPlan<LOGN>;
   static constexpr int TLS = LOGN >= 14 ? 4 : 2;
   static constexpr int TL_ENTRIES = (3 * PL::N / 4) >> TLS;
   static constexpr size_t LDS_BYTES = (size_t)PL::LDS_WORDS * sizeof(int32_t) + (size_t)TL_ENTRIES * sizeof(int2);
-  static constexpr int MINW = LOGN >= 14 ? 8 : (LOGN == 13 ? 6 : 7);   // waves per SIMD the register budget is cut for (2 x 16 / 3 x 8 waves per CU ... per SIMD)
+  // V: the plan's threads ("virtual threads", 16 points each) that one hardware thread runs side by side -- V = 2 halves the waves
+  // every exchange barrier has to collect and doubles the independent work between two barriers.  Same-box A/B, bit-exact either
+  // way: 16384 points V = 2 (two 512-thread workgroups per CU, 128 VGPRs) 0.515 -> 0.562 of the roofline, V = 4 0.54; 8192 points
+  // V = 2 0.66 -> 0.633, 4096 points 0.66 -> 0.64-0.66: those keep V = 1.
+  static constexpr int V = LOGN >= 14 ? ARMFFT_Q31_V14 : (LOGN == 13 ? ARMFFT_Q31_V13 : ARMFFT_Q31_V12);
+  static constexpr int TT = PL::T / V;                                  // hardware threads of the workgroup
+  static constexpr int MINW1 = LOGN >= 14 ? 8 : (LOGN == 13 ? 6 : 7);   // waves per SIMD the register budget is cut for (2 x 16 / 3 x 8 waves per CU ... per SIMD)
+  static constexpr int MINW = MINW1 / V > 0 ? MINW1 / V : 1;
 };
 
-// one exchange: x[c] leaves as word baseA + doff(c, LOGQA), x[c] returns as word baseB + doff(c, LOGQB)
-template <int LOGN, int LOGQA, int LOGQB>
-__device__ __forceinline__ void q31_exchange(int32_t *lds, int baseA, int baseB, Q31::cpx *x)
+// one exchange: x[v][c] leaves as word baseA[v] + doff(c, LOGQA), x[v][c] returns as word baseB[v] + doff(c, LOGQB)
+template <int LOGN, int LOGQA, int LOGQB, int V>
+__device__ __forceinline__ void q31_exchange(int32_t *lds, const int (&baseA)[V], const int (&baseB)[V], Q31::cpx (&x)[V][16])
 {
   using PL = DirectPlan<LOGN>;
 #pragma unroll
-  for (int c = 0; c < 16; c++) lds[baseA + PL::doff(c, LOGQA)] = x[c].re;
+  for (int v = 0; v < V; v++)
+#pragma unroll
+    for (int c = 0; c < 16; c++) lds[baseA[v] + PL::doff(c, LOGQA)] = x[v][c].re;
   __syncthreads();
 #pragma unroll
-  for (int c = 0; c < 16; c++) x[c].re = lds[baseB + PL::doff(c, LOGQB)];
+  for (int v = 0; v < V; v++)
+#pragma unroll
+    for (int c = 0; c < 16; c++) x[v][c].re = lds[baseB[v] + PL::doff(c, LOGQB)];
   __syncthreads();
 #pragma unroll
-  for (int c = 0; c < 16; c++) lds[baseA + PL::doff(c, LOGQA)] = x[c].im;
+  for (int v = 0; v < V; v++)
+#pragma unroll
+    for (int c = 0; c < 16; c++) lds[baseA[v] + PL::doff(c, LOGQA)] = x[v][c].im;
   __syncthreads();
 #pragma unroll
-  for (int c = 0; c < 16; c++) x[c].im = lds[baseB + PL::doff(c, LOGQB)];
+  for (int v = 0; v < V; v++)
+#pragma unroll
+    for (int c = 0; c < 16; c++) x[v][c].im = lds[baseB[v] + PL::doff(c, LOGQB)];
 }
 
-// steps from stage S on, the points in registers; (baseP, LOGQP) = where the previous step's outputs belong
-template <int LOGN, int S, bool INV, int LOGQP, bool FIRST>
-__device__ __forceinline__ void q31_split_steps(Q31::cpx *x, int32_t *lds, const int2 *tl, const int2 *__restrict__ tw, int tid, int baseP)
+// steps from stage S on, the points in registers; (baseP, LOGQP) = where the previous step's outputs belong; vt[v] = the plan's thread
+template <int LOGN, int S, bool INV, int LOGQP, bool FIRST, int V>
+__device__ __forceinline__ void q31_split_steps(Q31::cpx (&x)[V][16], int32_t *lds, const int2 *tl, const int2 *__restrict__ tw,
+                                                const int (&vt)[V], const int (&baseP)[V])
 {
   using PL = DirectPlan<LOGN>;
   constexpr int TLS = SplitQ31<LOGN>::TLS;
@@ -889,87 +914,107 @@ __device__ __forceinline__ void q31_split_steps(Q31::cpx *x, int32_t *lds, const
     constexpr bool PAIR = ((PL::M - 2 - S) % 2) == 0;
     constexpr int LOGN1 = PL::LOGL - 2 * S, LOGQ = LOGN1 - 4;
     constexpr bool LDS_S = ((PL::TWMOD0 << (2 * S)) & ((1 << TLS) - 1)) == 0;        // stage S's indices are multiples of 2^TLS
-    int blk, j;
-    dlane_map<LOGN, LOGN1>(tid, blk, j);
-    const int base = PL::pad((blk << LOGN1) + j);
-    q31_exchange<LOGN, LOGQP, LOGQ>(lds, baseP, base, x);
+    int base[V], jv[V];
+#pragma unroll
+    for (int v = 0; v < V; v++) {
+      int blk;
+      dlane_map<LOGN, LOGN1>(vt[v], blk, jv[v]);
+      base[v] = PL::pad((blk << LOGN1) + jv[v]);
+    }
+    q31_exchange<LOGN, LOGQP, LOGQ, V>(lds, baseP, base, x);
     // (compact tables for the last two middle stages, as in the q15 direct form, were measured here too: 4096 / 8192 points -2 %,
     // 16384 +-0 -- this kernel waits on its exchange barriers, not on the table reads)
-    if constexpr (PAIR) {
-      if constexpr (LDS_S) pair_butterflies<Q31, PL::LOGL, S, INV, PL::TWMOD0>(x, j, tld, tld);
-      else pair_butterflies<Q31, PL::LOGL, S, INV, PL::TWMOD0>(x, j, tg, tld);       // stage S + 1: multiples of 4 * 2^TLS at least
-    } else {
-      if constexpr (LDS_S) stage_butterflies<Q31, PL::LOGL, S, INV, PL::TWMOD0>(x, j, tld);
-      else stage_butterflies<Q31, PL::LOGL, S, INV, PL::TWMOD0>(x, j, tg);
+#pragma unroll
+    for (int v = 0; v < V; v++) {
+      if constexpr (PAIR) {
+        if constexpr (LDS_S) pair_butterflies<Q31, PL::LOGL, S, INV, PL::TWMOD0>(x[v], jv[v], tld, tld);
+        else pair_butterflies<Q31, PL::LOGL, S, INV, PL::TWMOD0>(x[v], jv[v], tg, tld);       // stage S + 1: multiples of 4 * 2^TLS at least
+      } else {
+        if constexpr (LDS_S) stage_butterflies<Q31, PL::LOGL, S, INV, PL::TWMOD0>(x[v], jv[v], tld);
+        else stage_butterflies<Q31, PL::LOGL, S, INV, PL::TWMOD0>(x[v], jv[v], tg);
+      }
     }
-    q31_split_steps<LOGN, S + (PAIR ? 2 : 1), INV, LOGQ, false>(x, lds, tl, tw, tid, base);
+    q31_split_steps<LOGN, S + (PAIR ? 2 : 1), INV, LOGQ, false, V>(x, lds, tl, tw, vt, base);
   } else {
-    // last step: block brev(tid); stage M-2 of the pair has uniform twiddles (j = 0): scalar loads from the global table
-    const int blk = (int)(__brev((unsigned)tid) >> (32 - PL::LOGT));
-    q31_exchange<LOGN, LOGQP, 0>(lds, baseP, PL::pad(blk << 4), x);
-    pair_butterflies<Q31, PL::LOGL, PL::M - 2, INV, PL::TWMOD0>(x, 0, tg, tg);
+    // last step: block brev(thread); stage M-2 of the pair has uniform twiddles (j = 0): scalar loads from the global table
+    int base[V];
+#pragma unroll
+    for (int v = 0; v < V; v++) base[v] = PL::pad((int)(__brev((unsigned)vt[v]) >> (32 - PL::LOGT)) << 4);
+    q31_exchange<LOGN, LOGQP, 0, V>(lds, baseP, base, x);
+#pragma unroll
+    for (int v = 0; v < V; v++) pair_butterflies<Q31, PL::LOGL, PL::M - 2, INV, PL::TWMOD0>(x[v], 0, tg, tg);
   }
 }
 
 template <int LOGN, bool INV>
-__global__ __launch_bounds__(DirectPlan<LOGN>::T, SplitQ31<LOGN>::MINW) void cfft_q31_split_kernel(int2 *__restrict__ data,
-                                                                                                  const int2 *__restrict__ tw, uint32_t batch)
+__global__ __launch_bounds__(SplitQ31<LOGN>::TT, SplitQ31<LOGN>::MINW) void cfft_q31_split_kernel(int2 *__restrict__ data,
+                                                                                              const int2 *__restrict__ tw, uint32_t batch)
 {
   using PL = DirectPlan<LOGN>;
   using SP = SplitQ31<LOGN>;
   using cpx = Q31::cpx;
   static_assert(PL::TPB == 1 && LOGN >= 12 && LOGN <= 14, "one transform per workgroup");
   static_assert(LOGN != 14 || (1 << SP::TLS) <= 16, "stage 2 onwards indexes the table in multiples of 16");
-  constexpr int W = sizeof(int2), T = PL::T, M = PL::M;
+  constexpr int W = sizeof(int2), T = PL::T, M = PL::M, V = SP::V, TT = SP::TT;
+  static_assert(TT * V == T && TT >= 64, "whole waves");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const uint32_t t0 = blockIdx.x + blockIdx.y * gridDim.x;
   if (t0 >= batch) return;
-  const int tid = threadIdx.x;
   int32_t *lds = reinterpret_cast<int32_t *>(lds_raw);
   int2 *tl = reinterpret_cast<int2 *>(lds + PL::LDS_WORDS);
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(data + (size_t)t0 * PL::N, 0, (int)(PL::N * W), 0x00020000);
-  const int voff = tid * W;
-  cpx x[16];
+  int vt[V], base0[V];
 #pragma unroll
-  for (int c = 0; c < 16; c++) x[c] = Q31::unpack(DirectIo<Q31>::load(rs, voff, c * T * W));
-  for (int i = tid; i < SP::TL_ENTRIES; i += T) tl[i] = tw[i << SP::TLS];
+  for (int v = 0; v < V; v++) vt[v] = (int)threadIdx.x + v * TT, base0[v] = PL::pad(vt[v]);
+  cpx x[V][16];
+#pragma unroll
+  for (int v = 0; v < V; v++)
+#pragma unroll
+    for (int c = 0; c < 16; c++) x[v][c] = Q31::unpack(DirectIo<Q31>::load(rs, vt[v] * W, c * T * W));
+  for (int i = threadIdx.x; i < SP::TL_ENTRIES; i += TT) tl[i] = tw[i << SP::TLS];
   // ---- first step on the loaded registers (as direct_transform) ----
   constexpr int S1 = (PL::BY2 || (M & 1)) ? 1 : 2;
-  if constexpr (PL::BY2) {
 #pragma unroll
-    for (int c = 0; c < 8; c++) by2<Q31, INV>(x[c], x[c + 8], Q31::unpack(tw[tid + c * T]));
+  for (int v = 0; v < V; v++) {
+    const int tid = vt[v];
+    cpx *xv = x[v];
+    if constexpr (PL::BY2) {
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
+      for (int c = 0; c < 8; c++) by2<Q31, INV>(xv[c], xv[c + 8], Q31::unpack(tw[tid + c * T]));
 #pragma unroll
-      for (int k = 0; k < 2; k++) {
-        cpx y[4] = {x[8 * h + k], x[8 * h + k + 2], x[8 * h + k + 4], x[8 * h + k + 6]};
-        const int ic = 2 * (tid + k * T);
-        bfly<Q31, 0, INV>(y, Q31::unpack(tw[ic]), Q31::unpack(tw[2 * ic]), Q31::unpack(tw[3 * ic]));
-        x[8 * h + k] = y[0]; x[8 * h + k + 2] = y[1]; x[8 * h + k + 4] = y[2]; x[8 * h + k + 6] = y[3];
+      for (int h = 0; h < 2; h++) {
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+          cpx y[4] = {xv[8 * h + k], xv[8 * h + k + 2], xv[8 * h + k + 4], xv[8 * h + k + 6]};
+          const int ic = 2 * (tid + k * T);
+          bfly<Q31, 0, INV>(y, Q31::unpack(tw[ic]), Q31::unpack(tw[2 * ic]), Q31::unpack(tw[3 * ic]));
+          xv[8 * h + k] = y[0]; xv[8 * h + k + 2] = y[1]; xv[8 * h + k + 4] = y[2]; xv[8 * h + k + 6] = y[3];
+        }
       }
-    }
-  } else if constexpr ((M & 1) == 0) {
-    auto tg = [&](int ic) { return tw[ic]; };
-    pair_butterflies<Q31, LOGN, 0, INV, 1>(x, tid, tg, tg);
-  } else {
+    } else if constexpr ((M & 1) == 0) {
+      auto tg = [&](int ic) { return tw[ic]; };
+      pair_butterflies<Q31, LOGN, 0, INV, 1>(xv, tid, tg, tg);
+    } else {
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      cpx y[4] = {x[k], x[4 + k], x[8 + k], x[12 + k]};
-      const int ic = tid + k * T;
-      bfly<Q31, 0, INV>(y, Q31::unpack(tw[ic]), Q31::unpack(tw[2 * ic]), Q31::unpack(tw[3 * ic]));
-      x[k] = y[0]; x[4 + k] = y[1]; x[8 + k] = y[2]; x[12 + k] = y[3];
+      for (int k = 0; k < 4; k++) {
+        cpx y[4] = {xv[k], xv[4 + k], xv[8 + k], xv[12 + k]};
+        const int ic = tid + k * T;
+        bfly<Q31, 0, INV>(y, Q31::unpack(tw[ic]), Q31::unpack(tw[2 * ic]), Q31::unpack(tw[3 * ic]));
+        xv[k] = y[0]; xv[4 + k] = y[1]; xv[8 + k] = y[2]; xv[12 + k] = y[3];
+      }
     }
   }
   // ---- the remaining steps, an exchange before each ----
-  q31_split_steps<LOGN, S1, INV, PL::LOGT, true>(x, lds, tl, tw, tid, PL::pad(tid));
+  q31_split_steps<LOGN, S1, INV, PL::LOGT, true, V>(x, lds, tl, tw, vt, base0);
 #pragma unroll
-  for (int c = 0; c < 16; c++) DirectIo<Q31>::store(Q31::pack(direct_out<Q31, LOGN>(x[c])), rs, voff, direct_rc(c) * T * W);
+  for (int v = 0; v < V; v++)
+#pragma unroll
+    for (int c = 0; c < 16; c++) DirectIo<Q31>::store(Q31::pack(direct_out<Q31, LOGN>(x[v][c])), rs, vt[v] * W, direct_rc(c) * T * W);
 }
 
 template <int LOGN, bool INV>
 static hipError_t launch_q31_split(int2 *data, const int2 *tw, uint32_t batch, hipStream_t stream)
 {
-  using PL = DirectPlan<LOGN>;
   constexpr size_t lds_bytes = SplitQ31<LOGN>::LDS_BYTES;
   static std::atomic<bool> attr_done[16];
   int dev = 0;
@@ -982,7 +1027,7 @@ static hipError_t launch_q31_split(int2 *data, const int2 *tw, uint32_t batch, h
   }
   const uint32_t gx = batch < 65536u ? batch : 65536u, gy = (batch + gx - 1) / gx;
   note_kernel(INV ? "cfft_q31_split_kernel<%d, true>" : "cfft_q31_split_kernel<%d, false>", false, LOGN);
-  kern<<<dim3(gx, gy, 1), PL::T, lds_bytes, stream>>>(data, tw, batch);
+  kern<<<dim3(gx, gy, 1), SplitQ31<LOGN>::TT, lds_bytes, stream>>>(data, tw, batch);
   return hipGetLastError();
 }
 
