@@ -224,6 +224,34 @@ struct CmpCnd2Spaced {
                      "v_add_u32 %2, %2, %3\n\tv_add_u32 %2, %2, %3\n\tv_cndmask_b32 %1, %1, %3, vcc" : "+v"(a), "+v"(i), "+v"(k) : "v"(b) : "vcc");
     }
 };
+struct Mul24Sdwa {
+    static constexpr const char* name = "v_mul_i32_i24_sdwa";
+    __device__ static void op(int& a, int b, long long&) {
+        asm volatile("v_mul_i32_i24_sdwa %0, sext(%0), sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1" : "+v"(a) : "v"(b));
+    }
+};
+struct MovSdwa {
+    static constexpr const char* name = "v_mov_b32_sdwa (sext word)";
+    __device__ static void op(int& a, int b, long long&) {
+        asm volatile("v_mov_b32_sdwa %0, sext(%0) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0" : "+v"(a));
+    }
+};
+struct BfeI32 {
+    static constexpr const char* name = "v_bfe_i32";
+    __device__ static void op(int& a, int b, long long&) { asm volatile("v_bfe_i32 %0, %0, 0, 16" : "+v"(a)); }
+};
+struct PkSubI16 {
+    static constexpr const char* name = "v_pk_sub_i16";
+    __device__ static void op(int& a, int b, long long&) { asm volatile("v_pk_sub_i16 %0, %0, %1" : "+v"(a) : "v"(b)); }
+};
+struct Bfi {
+    static constexpr const char* name = "v_bfi_b32";
+    __device__ static void op(int& a, int b, long long&) { asm volatile("v_bfi_b32 %0, %1, %0, %1" : "+v"(a) : "v"(b)); }
+};
+struct MadI32I16 {
+    static constexpr const char* name = "v_mad_i32_i16";
+    __device__ static void op(int& a, int b, long long&) { asm volatile("v_mad_i32_i16 %0, %0, %1, %1" : "+v"(a) : "v"(b)); }
+};
 struct MulHi {
     static constexpr const char* name = "v_mul_hi_i32";
     __device__ static void op(int& a, int b, long long&) { asm volatile("v_mul_hi_i32 %0, %0, %1" : "+v"(a) : "v"(b)); }
@@ -340,7 +368,7 @@ int main(int argc, char** argv) {
     ROW(SubF32) ROW(AddF32Diff) ROW(MulF32Sgpr) ROW(MulF32Const) ROW(MulF32Lit)
     ROW(AddF32) ROW(MulF32) ROW(FmacF32) ROW(MaxF32) ROW(FmaF32) ROW(PkAddF32) ROW(PkMulF32) ROW(PkFmaF32) ROW(FmaF64)
     ROW(SubI32) ROW(AddI32Clamp) ROW(MulHi) ROW(MulLo) ROW(Mad64) ROW(Mul24) ROW(MulHi24) ROW(Mad32_24) ROW(Dot2)
-    ROW(PkAddI16) ROW(PkAshr) ROW(Perm) ROW(Ashr64)
+    ROW(Mul24Sdwa) ROW(MovSdwa) ROW(BfeI32) ROW(MadI32I16) ROW(PkSubI16) ROW(Bfi) ROW(PkAddI16) ROW(PkAshr) ROW(Perm) ROW(Ashr64)
     CHECK(hipFree(out));
     return 0;
 }
