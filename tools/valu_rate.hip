@@ -252,6 +252,30 @@ struct MadI32I16 {
     static constexpr const char* name = "v_mad_i32_i16";
     __device__ static void op(int& a, int b, long long&) { asm volatile("v_mad_i32_i16 %0, %0, %1, %1" : "+v"(a) : "v"(b)); }
 };
+struct SqrtF32 {
+    static constexpr const char* name = "v_sqrt_f32";
+    __device__ static void op(int& a, int b, long long&) { asm volatile("v_sqrt_f32 %0, %0" : "+v"(a)); }
+};
+struct RcpF32 {
+    static constexpr const char* name = "v_rcp_f32";
+    __device__ static void op(int& a, int b, long long&) { asm volatile("v_rcp_f32 %0, %0" : "+v"(a)); }
+};
+struct MovDppShr {
+    static constexpr const char* name = "v_mov_b32_dpp row_shr:1";
+    __device__ static void op(int& a, int b, long long&) { asm volatile("v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a) : "v"(b)); }
+};
+struct MovDppBcast {
+    static constexpr const char* name = "v_mov_b32_dpp row_bcast:15";
+    __device__ static void op(int& a, int b, long long&) { asm volatile("v_mov_b32_dpp %0, %1 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(a) : "v"(b)); }
+};
+struct MovDppWave {
+    static constexpr const char* name = "v_mov_b32_dpp wave_shr:1";
+    __device__ static void op(int& a, int b, long long&) { asm volatile("v_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a) : "v"(b)); }
+};
+struct MaxDpp {
+    static constexpr const char* name = "v_max_f32_dpp quad_perm";
+    __device__ static void op(int& a, int b, long long&) { asm volatile("v_max_f32_dpp %0, %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(a) : "v"(b)); }
+};
 struct MulHi {
     static constexpr const char* name = "v_mul_hi_i32";
     __device__ static void op(int& a, int b, long long&) { asm volatile("v_mul_hi_i32 %0, %0, %1" : "+v"(a) : "v"(b)); }
@@ -368,7 +392,7 @@ int main(int argc, char** argv) {
     ROW(SubF32) ROW(AddF32Diff) ROW(MulF32Sgpr) ROW(MulF32Const) ROW(MulF32Lit)
     ROW(AddF32) ROW(MulF32) ROW(FmacF32) ROW(MaxF32) ROW(FmaF32) ROW(PkAddF32) ROW(PkMulF32) ROW(PkFmaF32) ROW(FmaF64)
     ROW(SubI32) ROW(AddI32Clamp) ROW(MulHi) ROW(MulLo) ROW(Mad64) ROW(Mul24) ROW(MulHi24) ROW(Mad32_24) ROW(Dot2)
-    ROW(Mul24Sdwa) ROW(MovSdwa) ROW(BfeI32) ROW(MadI32I16) ROW(PkSubI16) ROW(Bfi) ROW(PkAddI16) ROW(PkAshr) ROW(Perm) ROW(Ashr64)
+    ROW(SqrtF32) ROW(RcpF32) ROW(MovDppShr) ROW(MovDppBcast) ROW(MovDppWave) ROW(MaxDpp) ROW(Mul24Sdwa) ROW(MovSdwa) ROW(BfeI32) ROW(MadI32I16) ROW(PkSubI16) ROW(Bfi) ROW(PkAddI16) ROW(PkAshr) ROW(Perm) ROW(Ashr64)
     CHECK(hipFree(out));
     return 0;
 }
